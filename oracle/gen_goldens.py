@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REAL reference (imported read-only from /root/reference
+through oracle/ref_harness.py) on seeded inputs and writes small fixtures to tests/golden/.
+
+Run in the build container only:   python oracle/gen_goldens.py
+The fixtures are data (inputs are regenerated from legacy numpy RandomState seeds, outputs are
+stored); no reference source text is written anywhere.  Input recipes live in
+`oracle/golden_inputs.py` so that tests regenerate exactly the same inputs.
+"""
+import hashlib
+import json
+import os
+import random
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import golden_inputs as GI  # noqa: E402
+import ref_harness  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def nz_list(a):
+    rows, cols = np.nonzero(a)
+    return rows.astype(np.int16), cols.astype(np.int16), a[rows, cols]
+
+
+def gen_trajectories(ns, store):
+    for param in GI.PARAMS:
+        for seed in GI.TRAJ_SEEDS:
+            np.random.seed(seed)
+            tr = ns.generate_trajectory.Trajectory(canvas=256, max_len=96, expl=param).fit()
+            first = tr.x.copy()
+            tr = tr.fit()
+            key = "traj_p%g_s%d" % (param, seed)
+            store[key + "_fit1"] = first
+            store[key + "_fit2"] = tr.x.copy()
+            store[key + "_len"] = np.array([tr.tot_length, tr.big_expl_count], dtype=np.float64)
+            store[key + "_next"] = np.array([np.random.uniform(), np.random.randn()])
+    # expl=None constructor draw + a parameter with frequent big shakes (exercises the cexp branch)
+    np.random.seed(7)
+    tr = ns.generate_trajectory.Trajectory(canvas=64, iters=500, max_len=60).fit()
+    store["traj_none_s7"] = tr.x.copy()
+    store["traj_none_s7_expl"] = np.array([tr.expl, tr.tot_length, tr.big_expl_count])
+    np.random.seed(11)
+    tr = ns.generate_trajectory.Trajectory(canvas=256, iters=2000, max_len=96, expl=0.9).fit()
+    store["traj_big_s11"] = tr.x.copy()
+    store["traj_big_s11_len"] = np.array([tr.tot_length, tr.big_expl_count])
+
+
+def gen_psfs(ns, store):
+    for param in GI.PARAMS:
+        for fi, frac in enumerate(GI.FRACTIONS):
+            seed = GI.psf_seed(param, fi)
+            np.random.seed(seed)
+            tr = ns.generate_trajectory.Trajectory(canvas=256, max_len=96, expl=param).fit()
+            tr = tr.fit()
+            p = ns.generate_PSF.PSF(canvas=256, trajectory=tr, fraction=[frac])
+            raw = p.fit()[0].copy()
+            p.centerPSF()
+            cen = p.PSFs[0].copy()
+            crop = cen[64:192, 64:192].copy()
+            half = torch.HalfTensor(crop)
+            norm = half / half.sum()
+            key = "psf_p%g_f%d" % (param, fi)
+            for nm, arr in (("raw", raw), ("cen", cen), ("crop", crop)):
+                r, c, v = nz_list(arr)
+                store[key + "_%s_r" % nm], store[key + "_%s_c" % nm], store[key + "_%s_v" % nm] = r, c, v
+            r, c, v = nz_list(half.numpy())
+            store[key + "_half_r"], store[key + "_half_c"] = r, c
+            store[key + "_half_v"] = v.view(np.uint16)
+            nzp = norm.nonzero(as_tuple=False).numpy()
+            store[key + "_norm_rc"] = nzp.astype(np.int16)
+            store[key + "_norm_w"] = norm[nzp[:, 0], nzp[:, 1]].numpy().view(np.uint16)
+            store[key + "_sum"] = half.sum().numpy().reshape(1).view(np.uint16)
+    # multi-fraction cumulative list (PSF API parity, generate_PSF.py:39-77)
+    np.random.seed(5)
+    tr = ns.generate_trajectory.Trajectory(canvas=128, iters=300, max_len=40, expl=0.005).fit()
+    p = ns.generate_PSF.PSF(canvas=128, trajectory=tr, fraction=[1 / 100, 1 / 10, 1 / 2, 1])
+    for i, a in enumerate(p.fit()):
+        store["psf_multi_%d" % i] = a.copy()
+    store["psf_multi_traj"] = tr.x.copy()
+
+
+def gen_blur(ns, store, meta):
+    mb = ns.blur_functions.manual_blur
+    for case in GI.blur_cases():
+        img = GI.make_image(case)
+        psf = torch.from_numpy(GI.make_case_psf(case))   # normalised, dtype of the case
+        t_img = torch.from_numpy(img)
+        out = mb(t_img, psf).numpy()
+        name = "blur_" + case["name"]
+        if case.get("digest_only"):
+            meta[name] = {"sha256": hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest(),
+                          "shape": list(out.shape), "dtype": str(out.dtype)}
+            store[name + "_sample"] = np.ascontiguousarray(out[..., ::37, ::41]).view(
+                np.uint16 if out.dtype == np.float16 else np.uint32)
+        else:
+            store[name] = out.view(np.uint16 if out.dtype == np.float16 else np.uint32)
+        print("  blur case", case["name"], out.shape, out.dtype)
+    # blur_image_list: un-normalised PSFs, mixed blurring flags, ragged sizes
+    imgs, dicts, psfs = GI.make_list_case()
+    t_imgs = [torch.from_numpy(a) for a in imgs]
+    t_psfs = [torch.from_numpy(a) for a in psfs]
+    ret = ns.blur_functions.blur_image_list(t_imgs, dicts, t_psfs)
+    assert ret is None
+    for i, t in enumerate(t_imgs):
+        store["blurlist_%d" % i] = t.numpy().view(np.uint16)
+
+
+def gen_boxes(ns, store):
+    for case in GI.box_cases():
+        boxes, psf, shape = GI.make_box_case(case)
+        tgt = [{"boxes": torch.from_numpy(boxes.copy())}]
+        out = ns.utils.expand_targets(tgt, [{"blurring": True}], [torch.from_numpy(psf)],
+                                      [torch.zeros(shape, dtype=torch.float16)])
+        store["boxes_" + case["name"]] = out[0]["boxes"].numpy().view(np.uint32)
+    # fix_bounding_box_squeeze alone
+    b = GI.make_squeeze_boxes()
+    t = {"boxes": torch.from_numpy(b.copy())}
+    ns.utils.fix_bounding_box_squeeze(t, (3, 100, 150))
+    store["boxes_squeeze"] = t["boxes"].numpy().view(np.uint32)
+
+
+class _PsfTree:
+    """Creates, on demand, only the stored-PSF files a seeded reference call will open."""
+
+    def __init__(self, root):
+        self.root = root
+
+    def ensure(self, p, e, idx):
+        d = os.path.join(self.root, "P%dE%d" % (p, e))
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "I%06d" % idx)
+        if not os.path.exists(path):
+            with open(path, "wb") as f:
+                np.save(f, GI.stored_psf(p, e, idx))
+        return path
+
+
+def gen_blurdicts(ns, meta, store):
+    BlurImage = ns.transforms.BlurImage
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="dib_psfs_")
+    tree = _PsfTree(tmp)
+    for mode in GI.blurimage_modes():
+        kw = dict(mode["kwargs"])
+        if kw.get("use_stored_psfs"):
+            kw["stored_psf_directory"] = tmp
+        recs = []
+        random.seed(mode["seed"])
+        np.random.seed(mode["seed"])
+        bi = BlurImage(blur_image_in_transform=False, **kw)
+        for call in range(mode["calls"]):
+            if kw.get("use_stored_psfs"):
+                # the reference opens P{p}E{e}/I{idx}: pre-create exactly that file by
+                # replaying the documented draw order on a copy of the RNG state
+                st = random.getstate()
+                pred = GI.predict_stored_draw(kw)
+                random.setstate(st)
+                if pred is not None:
+                    tree.ensure(*pred)
+            img, tgt, bd = bi("IMG", {"t": call}, {})
+            rec = {"blurring": bool(bd["blurring"])}
+            if bd["blurring"]:
+                psf = np.asarray(bd["psf"])
+                r, c, v = nz_list(psf)
+                k = "bd_%s_%d" % (mode["name"], call)
+                store[k + "_r"], store[k + "_c"] = r, c
+                store[k + "_v"] = v
+                rec.update(psf_dtype=str(psf.dtype), psf_shape=list(psf.shape),
+                           theta_rad=float(bd["theta_rad"]).hex(),
+                           scale_factor_lambda1=float(bd["scale_factor_lambda1"]).hex(),
+                           scale_factor_lambda2=float(bd["scale_factor_lambda2"]).hex(),
+                           param_index=None if bd["param_index"] is None else int(bd["param_index"]),
+                           fraction_index=None if bd["fraction_index"] is None else int(bd["fraction_index"]))
+            else:
+                rec.update(psf=list(bd["psf"]), theta_rad=bd["theta_rad"],
+                           scale_factor_lambda1=bd["scale_factor_lambda1"],
+                           scale_factor_lambda2=bd["scale_factor_lambda2"],
+                           param_index=bd["param_index"], fraction_index=bd["fraction_index"])
+            assert img == "IMG" and tgt == {"t": call}
+            recs.append(rec)
+        out[mode["name"]] = {"records": recs, "next_random": random.random(),
+                             "next_np": float(np.random.uniform())}
+    # preBlurred pass-through (transforms.py:225-235)
+    bi = BlurImage(prob=1.0, blur_image_in_transform=False)
+    _, _, bd = bi("IMG", None, {"preBlurred": True})
+    out["preblurred"] = {k: (v if not isinstance(v, np.generic) else v.item()) for k, v in bd.items()}
+    meta["blurimage"] = out
+
+
+def gen_norm(ns, store):
+    dicts = GI.norm_dicts()
+    for flag in (False, True):
+        m, s = ns.utils.get_norm_params(dicts, flag)
+        store["norm_means_%d" % flag] = m
+        store["norm_stds_%d" % flag] = s
+    m, s = ns.utils.get_norm_params(None, True)
+    store["norm_none_means"], store["norm_none_stds"] = m, s
+
+
+def gen_fft(ns, store):
+    from PIL import Image
+    img = GI.make_fft_image()
+    psf = GI.make_fft_psf()
+    h = ns.blur_image.BlurImageHandler(image_path=None, PSFs=[psf.astype(np.float32)],
+                                       pillowImage=Image.fromarray(img))
+    assert h.blur_image()
+    store["fft_out"] = np.array(h.pilImageResult)
+
+
+def main():
+    ns = ref_harness.load()
+    os.makedirs(OUT, exist_ok=True)
+    meta = {"numpy": np.__version__, "torch": torch.__version__}
+    for name, fn in (("traj", gen_trajectories), ("psf", gen_psfs), ("boxes", gen_boxes),
+                     ("norm", gen_norm), ("fft", gen_fft)):
+        store = {}
+        fn(ns, store)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+        print(name, len(store), "arrays")
+    store = {}
+    gen_blur(ns, store, meta)
+    np.savez_compressed(os.path.join(OUT, "blur.npz"), **store)
+    store = {}
+    gen_blurdicts(ns, meta, store)
+    np.savez_compressed(os.path.join(OUT, "blurdict.npz"), **store)
+    with open(os.path.join(OUT, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

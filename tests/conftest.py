@@ -1,0 +1,47 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests are skipped (not failed) when no device is visible, e.g. a plain `pytest tests/`
+    in the CPU container; `-m gpu` on the GPU box runs them."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    import json
+    d = os.path.join(ROOT, "tests", "golden")
+
+    class G:
+        traj = np.load(os.path.join(d, "traj.npz"))
+        psf = np.load(os.path.join(d, "psf.npz"))
+        blur = np.load(os.path.join(d, "blur.npz"))
+        boxes = np.load(os.path.join(d, "boxes.npz"))
+        norm = np.load(os.path.join(d, "norm.npz"))
+        fft = np.load(os.path.join(d, "fft.npz"))
+        blurdict = np.load(os.path.join(d, "blurdict.npz"))
+        meta = json.load(open(os.path.join(d, "meta.json")))
+    return G
