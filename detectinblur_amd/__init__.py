@@ -1,0 +1,10 @@
+"""detectinblur_amd: MI355X-native implementation of detectInBlur's `--gpu_blur` hot path.
+
+Module names mirror the reference (mohammed-amr/detectInBlur) so call sites read the same:
+    detectinblur_amd.models.blur_functions.blur_image_list / manual_blur
+    detectinblur_amd.utils.expand_targets / fix_bounding_box_squeeze / get_norm_params
+    detectinblur_amd.transforms.BlurImage, detectinblur_amd.motion_blur.*
+All device work goes through the C ABI of include/dib.h (libdib_hip.so, hand-written HIP for
+gfx950); there is no CPU fallback.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,79 @@
+"""ctypes binding of libdib_hip.so (C ABI: include/dib.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, importing
+any compute entry point raises.  The CPU oracle under oracle/ is test infrastructure and is
+never imported from this package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
+
+DIB_F16, DIB_F32 = 0, 1
+DIB_ACC_BITEXACT, DIB_ACC_FP32 = 0, 1
+DIB_ESHAPE, DIB_ENOT128 = -2, -4
+
+_lib = None
+
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+_SIGNATURES = {
+    "dib_abi_version": (ctypes.c_int, []),
+    "dib_last_error": (ctypes.c_char_p, []),
+    "dib_tap_table_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "dib_psf_compact": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_sparse_blur": (ctypes.c_int, [_c_void_pp, _c_void_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "dib_expand_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p]),
+    "dib_clamp_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "dib_psf_rasterize_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "dib_psf_rasterize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
+    # test hook, not part of the drop-in boundary
+    "dib_sparse_blur_generic": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.c_void_p]),
+}
+
+EXPORTS = tuple(k for k in _SIGNATURES if k != "dib_sparse_blur_generic")
+
+
+class DibError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libdib_hip: %s (code %d)" % (text, code))
+        self.code = code
+
+
+def lib():
+    """Loads libdib_hip.so once.  Raises if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError("%s not found: build it with `make -C detectinblur_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        if l.dib_abi_version() != 1:
+            raise ImportError("libdib_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise DibError(code, lib().dib_last_error().decode("utf-8", "replace"))
+
+
+def int_array(values):
+    return (ctypes.c_int * len(values))(*values)
+
+
+def ptr_array(values):
+    return (ctypes.c_void_p * len(values))(*values)

@@ -1,0 +1,74 @@
+// Shared declarations for the gfx950 kernels behind include/dib.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dib.h"
+
+namespace dib {
+
+// ---- tap-table layout (see include/dib.h) ------------------------------------------------
+constexpr int HDR_NTAPS = 0, HDR_RMIN = 1, HDR_RMAX = 2, HDR_CMIN = 3, HDR_CMAX = 4, HDR_K = 5,
+              HDR_SUM = 6, HDR_FLAGS = 7, HDR_WORDS = 8;
+
+__host__ __device__ inline int table_rowptr_off() { return HDR_WORDS; }
+__host__ __device__ inline int table_taps_off(int K) { return (HDR_WORDS + K + 1 + 1) & ~1; }
+__host__ __device__ inline int table_words(int K) { return table_taps_off(K) + 2 * K * K; }
+
+// ---- padding modes of manual_blur (models/blur_functions.py:28-31, :55-58) ---------------
+enum PadMode { PAD_REFLECT = 0, PAD_ZERO = 1, PAD_REPLICATE = 2 };
+
+__host__ __device__ inline int pad_mode_for(int K, int H, int W) {
+  if (K > 129) return PAD_REPLICATE;
+  return (H < 64 || W < 64) ? PAD_ZERO : PAD_REFLECT;
+}
+
+// Maps a virtual (un-padded) coordinate s in [-pa, n-1+pb] to a source index in [0, n).
+// s == -pa is the circular-wrap row/column of torch.roll on the padded image:
+// it reads padded index n+K-2, i.e. virtual coordinate n+pb.  `zero` reports a zero-fill read.
+// Coordinates past n-1+pb (lanes outside the image) are clamped; their results are never stored.
+__device__ inline int map_coord(int s, int n, int pa, int pb, int mode, bool &zero) {
+  if (s == -pa) s = n + pb;
+  zero = false;
+  if (mode == PAD_REFLECT) {
+    if (s < 0) s = -s;
+    if (s > n - 1) s = 2 * (n - 1) - s;
+  } else if (mode == PAD_ZERO) {
+    zero = (s < 0) || (s > n - 1);
+  }
+  return min(max(s, 0), n - 1);
+}
+
+void set_error(const char *fmt, ...);
+
+#define DIB_HIP_CHECK(expr)                                                          \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      dib::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return DIB_EHIP;                                                               \
+    }                                                                                \
+  } while (0)
+
+// Per-launch image descriptors travel by value in the kernel argument buffer (no H2D copy,
+// no host sync).  MAX_BATCH images per launch; larger batches are split by the host wrapper.
+constexpr int MAX_BATCH = 32;
+
+struct ImageDesc {
+  const void *in;
+  void *out;
+  int C, H, W;
+  int table;       // index into the table array
+  int tile_begin;  // first flattened tile id of this image in the launch
+  int tiles_x;     // 256-px-wide tiles per row
+  int tiles_y32;   // 32-row tiles per channel (upper bound; 64-row classes use half of them)
+};
+
+struct BlurBatch {
+  ImageDesc img[MAX_BATCH];
+  int n;
+  int total_tiles;
+};
+
+}  // namespace dib

@@ -1,0 +1,223 @@
+/* Host-side native code (see include/dib_host.h).  Plain C99 + libm; built with
+ * -ffp-contract=off so every operation below rounds exactly once, as numpy's scalar math does. */
+#include <complex.h>
+#include <math.h>
+#include <stddef.h>
+
+#include "../../../include/dib_host.h"
+
+/* ---- MT19937 (Matsumoto & Nishimura) in numpy's legacy layout ---------------------------- */
+static void mt_refill(dib_mt19937 *s) {
+  const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAT = 0x9908b0dfu;
+  uint32_t *k = s->key, y;
+  int i;
+  for (i = 0; i < 624 - 397; i++) {
+    y = (k[i] & UPPER) | (k[i + 1] & LOWER);
+    k[i] = k[i + 397] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
+  }
+  for (; i < 623; i++) {
+    y = (k[i] & UPPER) | (k[i + 1] & LOWER);
+    k[i] = k[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
+  }
+  y = (k[623] & UPPER) | (k[0] & LOWER);
+  k[623] = k[396] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
+  s->pos = 0;
+}
+
+static inline uint32_t mt_next32(dib_mt19937 *s) {
+  uint32_t y;
+  if (s->pos >= 624) mt_refill(s);
+  y = s->key[s->pos++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+/* 53-bit double in [0,1): numpy's mt19937_next_double */
+double dib_rng_uniform(dib_mt19937 *s) {
+  uint32_t a = mt_next32(s) >> 5, b = mt_next32(s) >> 6;
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+/* numpy's legacy_gauss: polar method, second deviate cached */
+double dib_rng_gauss(dib_mt19937 *s) {
+  if (s->has_gauss) {
+    double t = s->gauss;
+    s->has_gauss = 0;
+    s->gauss = 0.0;
+    return t;
+  }
+  double f, x1, x2, r2;
+  do {
+    x1 = 2.0 * dib_rng_uniform(s) - 1.0;
+    x2 = 2.0 * dib_rng_uniform(s) - 1.0;
+    r2 = x1 * x1 + x2 * x2;
+  } while (r2 >= 1.0 || r2 == 0.0);
+  f = sqrt(-2.0 * log(r2) / r2);
+  s->gauss = f * x1;
+  s->has_gauss = 1;
+  return f * x2;
+}
+
+/* np.abs(complex128) as numpy >= 1.25 evaluates it: max * sqrt(fma(q, q, 1)), q = min / max */
+static inline double cabs_np(double re, double im) {
+  double a = fabs(re), b = fabs(im), mx = a >= b ? a : b, mn = a >= b ? b : a;
+  if (mx == 0.0) return 0.0;
+  double q = mn / mx;
+  return mx * sqrt(fma(q, q, 1.0));
+}
+
+int dib_trajectory_fit(dib_mt19937 *rng, int canvas, int iters, double max_len, double expl, double *x_out,
+                       double *unprocessed_out, double *stats_out) {
+  if (!rng || !x_out || iters < 2) return -1;
+  /* generate_trajectory.py:48-56 */
+  const double centripetal = 0.7 * dib_rng_uniform(rng);
+  const double prob_big_shake = 0.2 * dib_rng_uniform(rng);
+  const double gaussian_shake = 10 * dib_rng_uniform(rng);
+  const double init_angle = 360 * dib_rng_uniform(rng);
+  const double rad = init_angle * (M_PI / 180.0);
+  const double v0_im = sin(rad), v0_re = cos(rad);
+  const double step = max_len / (double)(iters - 1);
+  double v_re = (v0_re * max_len) / (double)(iters - 1), v_im = (v0_im * max_len) / (double)(iters - 1); /* :59 */
+  if (expl > 0) { v_re = v0_re * expl; v_im = v0_im * expl; }                                          /* :61-62 */
+  const double thr = prob_big_shake * expl;
+  double xr = 0.0, xi = 0.0, tot = 0.0;
+  long big = 0;
+  x_out[0] = 0.0; x_out[1] = 0.0;
+  for (int t = 0; t < iters - 1; ++t) {
+    double nd_re = 0.0, nd_im = 0.0;
+    if (dib_rng_uniform(rng) < thr) {                                                                /* :69 */
+      double complex e = cexp((M_PI + (dib_rng_uniform(rng) - 0.5)) * I);                             /* :70 */
+      double a_re = 2 * v_re, a_im = 2 * v_im, e_re = creal(e), e_im = cimag(e);
+      nd_re = a_re * e_re - a_im * e_im;
+      nd_im = a_re * e_im + a_im * e_re;
+      big++;
+    }
+    const double g_re = dib_rng_gauss(rng), g_im = dib_rng_gauss(rng);                                /* :76 */
+    const double in_re = gaussian_shake * g_re - centripetal * xr;
+    const double in_im = gaussian_shake * g_im - centripetal * xi;
+    const double dv_re = nd_re + (expl * in_re) * step, dv_im = nd_im + (expl * in_im) * step;        /* :75-77 */
+    v_re = v_re + dv_re;                                                                               /* :79 */
+    v_im = v_im + dv_im;
+    const double scl = 1.0 / cabs_np(v_re, v_im); /* numpy complex / real = times the reciprocal (:80) */
+    v_re = (v_re * scl) * step;
+    v_im = (v_im * scl) * step;
+    const double nr = xr + v_re, ni = xi + v_im;                                                       /* :81 */
+    tot = tot + hypot(nr - xr, ni - xi);                                                               /* :82 */
+    xr = nr; xi = ni;
+    x_out[2 * (t + 1)] = xr;
+    x_out[2 * (t + 1) + 1] = xi;
+  }
+  const double shift = canvas / 2.0;                                                                   /* :92 */
+  for (int t = 0; t < iters; ++t) {
+    if (unprocessed_out) { unprocessed_out[2 * t] = x_out[2 * t]; unprocessed_out[2 * t + 1] = x_out[2 * t + 1]; }
+    x_out[2 * t] = x_out[2 * t] + shift;
+    x_out[2 * t + 1] = x_out[2 * t + 1] + shift;
+  }
+  if (stats_out) { stats_out[0] = tot; stats_out[1] = (double)big; }
+  return 0;
+}
+
+/* ---- PSF.fit on the host (generate_PSF.py:31-83) ------------------------------------------- */
+static double sample_weight(int t, double frac, double prev, int iters) {
+  const double fn = frac * iters, pn = prev * iters; /* :47-56 */
+  if (fn >= t && pn < t - 1) return 1.0;
+  if (fn >= t - 1 && pn < t - 1) return fn - (t - 1);
+  if (fn >= t && pn < t) return t - pn;
+  if (fn >= t - 1 && pn < t) return (frac - prev) * iters;
+  return 0.0;
+}
+
+static inline double tri(double u) { double v = 1.0 - fabs(u); return v > 0.0 ? v : 0.0; }
+
+int dib_psf_fit(const double *traj, int iters, const double *fractions, int nfrac, int canvas, double *psfs_out) {
+  if (!traj || !fractions || !psfs_out || iters <= 0 || nfrac <= 0 || canvas < 3) return -1;
+  const size_t n = (size_t)canvas * canvas;
+  double *acc = psfs_out + (size_t)(nfrac - 1) * n; /* the shared accumulator lives in the last slot */
+  for (size_t i = 0; i < n; ++i) acc[i] = 0.0;
+  for (int j = 0; j < nfrac; ++j) {
+    const double prev = j == 0 ? 0.0 : fractions[j - 1];
+    for (int t = 0; t < iters; ++t) {
+      const double w = sample_weight(t, fractions[j], prev, iters);
+      const double re = traj[2 * t], im = traj[2 * t + 1];
+      double fr = floor(re), fi = floor(im);
+      int m2 = (int)(fr < 1 ? 1 : (fr > canvas - 1 ? canvas - 1 : fr)); /* :59 */
+      int m1 = (int)(fi < 1 ? 1 : (fi > canvas - 1 ? canvas - 1 : fi)); /* :61 */
+      if (m1 + 1 >= canvas || m2 + 1 >= canvas) return -2;              /* IndexError in the reference */
+      acc[(size_t)m1 * canvas + m2] += w * (tri(re - m2) * tri(im - m1));                 /* :64-75 */
+      acc[(size_t)m1 * canvas + m2 + 1] += w * (tri(re - (m2 + 1)) * tri(im - m1));
+      acc[(size_t)(m1 + 1) * canvas + m2] += w * (tri(re - m2) * tri(im - (m1 + 1)));
+      acc[(size_t)(m1 + 1) * canvas + m2 + 1] += w * (tri(re - (m2 + 1)) * tri(im - (m1 + 1)));
+    }
+    double *out = psfs_out + (size_t)j * n;
+    if (j == nfrac - 1) {
+      for (size_t i = 0; i < n; ++i) acc[i] = acc[i] / iters;           /* :77 (last: in place) */
+    } else {
+      for (size_t i = 0; i < n; ++i) out[i] = acc[i] / iters;
+    }
+  }
+  return 0;
+}
+
+/* numpy's DOUBLE_pairwise_sum over contiguous data */
+static double pairwise(const double *a, size_t n) {
+  if (n < 8) {
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += a[i];
+    return s;
+  }
+  if (n <= 128) {
+    double r[8];
+    size_t i;
+    for (i = 0; i < 8; ++i) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  size_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return pairwise(a, n2) + pairwise(a + n2, n - n2);
+}
+
+/* np.sum of a contiguous float64 array: 8192-element iterator chunks, left to right */
+static double numpy_sum(const double *a, size_t n) {
+  double s = 0.0;
+  for (size_t i = 0; i < n; i += 8192) s += pairwise(a + i, n - i < 8192 ? n - i : 8192);
+  return s;
+}
+
+int dib_psf_center(double *psf, int canvas, int *offsets_out) {
+  if (!psf || canvas <= 0) return -1;
+  const size_t n = (size_t)canvas * canvas;
+  const double total = numpy_sum(psf, n);                               /* :108 */
+  double ax = 0.0, ay = 0.0;
+  for (int r = 0; r < canvas; ++r)
+    for (int c = 0; c < canvas; ++c) {
+      const double v = psf[(size_t)r * canvas + c];
+      if (v > 0) {                                                      /* :110-117 */
+        const double w = v / total;
+        ax += (double)c * w;
+        ay += (double)r * w;
+      }
+    }
+  const int ox = (int)(ax - canvas / 2.0), oy = (int)(ay - canvas / 2.0); /* :119-120 */
+  if (offsets_out) { offsets_out[0] = ox; offsets_out[1] = oy; }
+  if (ox == 0 && oy == 0) return 0;
+  /* np.roll(-ox, axis=1) then np.roll(-oy, axis=0): out[r][c] = in[(r+oy) mod n][(c+ox) mod n] */
+  double *tmp = (double *)__builtin_malloc(n * sizeof(double));
+  if (!tmp) return -3;
+  for (int r = 0; r < canvas; ++r) {
+    int sr = ((r + oy) % canvas + canvas) % canvas;
+    for (int c = 0; c < canvas; ++c) {
+      int sc = ((c + ox) % canvas + canvas) % canvas;
+      tmp[(size_t)r * canvas + c] = psf[(size_t)sr * canvas + sc];
+    }
+  }
+  for (size_t i = 0; i < n; ++i) psf[i] = tmp[i];
+  __builtin_free(tmp);
+  return 0;
+}

@@ -1,0 +1,95 @@
+"""`--gpu_blur`: drop-in for the reference's models/blur_functions.py.
+
+Same names, argument meaning and return conventions as the reference:
+  * manual_blur(image_GPU, psf_GPU, ...)            reference models/blur_functions.py:11-89
+  * blur_image_list(images_GPU, blur_dicts, psfs_GPU, ...)   reference :92-100
+The Python roll loop (10 launches + 2 host syncs per tap) is replaced by two stream-ordered
+launches per batch through libdib_hip.so: tap compaction and the tiled sparse correlation.
+Results are bit-identical to the reference's Half arithmetic (tests/test_blur_gpu.py).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib, blur_ops
+
+
+def _post_ops(output, add_noise, noise_level, add_block, add_jpeg_artifact, jpeg_compressor):
+    # reference models/blur_functions.py:72-87 -- stock torch ops, same RNG draw order
+    if add_noise:
+        noise_var = np.random.uniform(0.00000001, noise_level)
+        output = torch.clamp(output + (torch.randn_like(output) * math.sqrt(noise_var)), 0, 1)
+    if add_block:
+        if np.random.uniform(0, 1) > 0.5:
+            original_shape = output.shape
+            scale_factor = np.random.uniform(0.6, 1)
+            output = torch.nn.functional.interpolate(output.unsqueeze(0), scale_factor=(scale_factor, scale_factor),
+                                                     mode="nearest").squeeze()
+            output = torch.nn.functional.interpolate(output.unsqueeze(0), size=original_shape[1:],
+                                                     mode="nearest").squeeze()
+    if add_jpeg_artifact:
+        if np.random.uniform(0, 1) > 0.35:
+            quality = np.random.uniform(20, 90)
+            from .. import transforms
+            output = transforms.add_jpeg_artifact_to_image(output, jpeg_compressor, quality)
+    return output
+
+
+def _check_shapes(image_GPU, K):
+    H, W = image_GPU.shape[-2], image_GPU.shape[-1]
+    if K <= 129 and not (H < 64 or W < 64) and (H == 64 or W == 64):
+        # what F.pad(mode='reflect') raises in the reference (blur_functions.py:59)
+        raise RuntimeError("Padding size should be less than the corresponding input dimension, "
+                           "but got: padding (63, 64) at dimension of input %s" % list(image_GPU.shape))
+
+
+def manual_blur(image_GPU, psf_GPU, add_noise=False, noise_level=0.001, add_block=False,
+                add_jpeg_artifact=False, jpeg_compressor=None, acc_mode=_lib.DIB_ACC_BITEXACT):
+    """image: C x H x W; psf: k x k with k = 128 or 256, already normalised (sums to one).
+    Returns the blurred image with every size-1 dim squeezed, like the reference (:69)."""
+    K = psf_GPU.shape[0]
+    _check_shapes(image_GPU, K)
+    if psf_GPU.dtype != image_GPU.dtype:
+        psf_GPU = psf_GPU.to(image_GPU.dtype)   # torch's `roll(image) * psf[r, c]` promotes a 0-dim tensor this way
+    tables = blur_ops.compact_psfs([psf_GPU], normalize=False)
+    out = blur_ops.sparse_blur([image_GPU], [0], tables, acc_mode)[0]
+    out = out.squeeze()
+    return _post_ops(out, add_noise, noise_level, add_block, add_jpeg_artifact, jpeg_compressor)
+
+
+def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_level=0.001, add_block=False,
+                    add_jpeg_artifact=False, jpeg_compressor=None, acc_mode=_lib.DIB_ACC_BITEXACT):
+    """In place: images_GPU[i] is replaced by its blurred version when blur_dicts[i]["blurring"].
+    PSFs arrive un-normalised and are divided by their sum here (reference :98).  Returns None."""
+    idx = [i for i, bd in enumerate(blur_dicts) if bd["blurring"]]
+    if not idx:
+        return None
+    Ks = {psfs_GPU[i].shape[0] for i in idx}
+    dts = {psfs_GPU[i].dtype for i in idx}
+    if len(Ks) != 1 or len(dts) != 1:
+        # mixed canvases / dtypes in one batch: one launch group per (K, dtype)
+        for K in Ks:
+            for dt in dts:
+                sub = [i for i in idx if psfs_GPU[i].shape[0] == K and psfs_GPU[i].dtype == dt]
+                if sub:
+                    _blur_group(images_GPU, psfs_GPU, sub, acc_mode)
+    else:
+        _blur_group(images_GPU, psfs_GPU, idx, acc_mode)
+    if add_noise or add_block or add_jpeg_artifact:
+        for i in idx:
+            images_GPU[i] = _post_ops(images_GPU[i], add_noise, noise_level, add_block, add_jpeg_artifact,
+                                      jpeg_compressor)
+    return None
+
+
+def _blur_group(images_GPU, psfs_GPU, idx, acc_mode):
+    K = psfs_GPU[idx[0]].shape[0]
+    for i in idx:
+        _check_shapes(images_GPU[i], K)
+    psfs = [psfs_GPU[i] if psfs_GPU[i].dtype == images_GPU[i].dtype else psfs_GPU[i].to(images_GPU[i].dtype)
+            for i in idx]
+    tables = blur_ops.compact_psfs_cached(psfs, normalize=True)
+    outs = blur_ops.sparse_blur([images_GPU[i] for i in idx], list(range(len(idx))), tables, acc_mode)
+    for k, i in enumerate(idx):
+        images_GPU[i] = outs[k].squeeze()

@@ -1,0 +1,106 @@
+/*
+ * dib.h -- C ABI of libdib_hip.so: the MI355X (gfx950) implementation of detectInBlur's
+ * data-parallel hot path (motion-blur augmentation feeding Faster R-CNN).
+ *
+ * The reference (mohammed-amr/detectInBlur) is pure Python; it has no FFI.  Each entry point
+ * below replaces the body of one reference function and is what a ctypes binding inside the
+ * reference would call.  Conventions:
+ *   - plain pointers and sizes only; no torch / C++ types cross the boundary;
+ *   - every `*_dev` pointer is device memory owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); host arrays are read during the call and may be freed on return;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); all work is
+ *     enqueued on it, no entry point synchronises the host or allocates device memory;
+ *   - return 0 on success, a negative DIB_E* code otherwise; dib_last_error() gives the text
+ *     (thread-local).  No C++ exception crosses the boundary.
+ */
+#ifndef DIB_H_
+#define DIB_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIB_ABI_VERSION 1
+
+/* error codes */
+#define DIB_OK 0
+#define DIB_EINVAL (-1)  /* bad argument (NULL pointer, unsupported K / dtype, ...)            */
+#define DIB_ESHAPE (-2)  /* reference would raise: reflect padding needs H,W > 64 (or < 64)    */
+#define DIB_EHIP (-3)    /* a HIP runtime call failed; text in dib_last_error()                */
+#define DIB_ENOT128 (-4) /* expand_targets on a PSF that is not 128 wide (utils.py:369-370)    */
+
+/* element types */
+#define DIB_F16 0
+#define DIB_F32 1
+
+/* accumulation modes of the sparse blur */
+#define DIB_ACC_BITEXACT 0 /* reference arithmetic: round after every multiply and every add,
+                              taps in row-major order (blur_functions.py:66-67)               */
+#define DIB_ACC_FP32 1     /* fp32 accumulate, one final rounding (fp16 images only)           */
+
+int dib_abi_version(void);
+const char *dib_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Tap tables.  A tap table is the device-side compacted form of one K x K PSF: header,
+ * CSR row pointers and the row-major list of non-zero taps {row, col, weight}.  It is produced
+ * once per PSF by dib_psf_compact and consumed by the blur and by the box growth, replacing the
+ * two `psf/psf.sum()` + `psf.nonzero()` passes of the reference
+ * (models/blur_functions.py:63,98 and utils.py:372-374) and their host synchronisations.
+ * Layout (int32 words): [0]=ntaps [1]=rmin [2]=rmax [3]=cmin [4]=cmax [5]=K [6]=sum bits
+ * [7]=flags | rowptr[K+1] | pad to even | taps[K*K] as {uint32 (row<<8|col), uint32 weight bits}.
+ * ------------------------------------------------------------------------------------- */
+size_t dib_tap_table_bytes(int K); /* bytes of ONE table; K is 128 or 256 */
+
+/* psf_dev: [B][K][K] of `dtype`.  normalize != 0 divides by the PSF's sum first, in the PSF's
+ * dtype, exactly like `psf_GPU / psf_GPU.sum()` (blur_functions.py:98, utils.py:372); 0 takes the
+ * weights as they are (manual_blur's contract, blur_functions.py:13).  tables_dev receives B
+ * tables, dib_tap_table_bytes(K) apart. */
+int dib_psf_compact(const void *psf_dev, int dtype, int B, int K, int normalize,
+                    void *tables_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sparse PSF (x) image correlation: models/blur_functions.py:11-69 (`manual_blur`, both canvas
+ * branches, post-ops excluded) for a whole batch in one launch; with tables built by
+ * dib_psf_compact(normalize=1) it is `blur_image_list` (blur_functions.py:92-100).
+ * Host arrays of length B: in/out device pointers (C x H x W planar, `dtype`, contiguous;
+ * out must not alias in), C, H, W and table_index (which table of tables_dev image i uses;
+ * < 0 = leave the image untouched, i.e. blur_dict["blurring"] == False).  Padding mode follows
+ * the reference: K = 256 -> replicate; K = 128 -> zero if H < 64 or W < 64, else reflect.
+ * Returns DIB_ESHAPE where the reference raises (K = 128 and H or W == 64).
+ * ------------------------------------------------------------------------------------- */
+int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, const int *C, const int *H,
+                    const int *W, const int *table_index, int B, int dtype,
+                    const void *tables_dev, int K, int acc_mode, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Box growth and clamping: utils.py:360-392 (`expand_targets`, one image) and utils.py:395-434
+ * (`fix_bounding_box_squeeze`).  boxes_dev: [N][4] float32 xyxy, updated in place.
+ * ------------------------------------------------------------------------------------- */
+int dib_expand_boxes(float *boxes_dev, int N, const void *table_dev, int H, int W, void *stream);
+int dib_clamp_boxes(float *boxes_dev, int N, int H, int W, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * PSF rasteriser: motion_blur/generate_PSF.py:31-83 (`PSF.fit`, single exposure fraction) and
+ * :106-123 (`centerPSF`), then the centre crop of transforms.py:334-335, batched.
+ * traj_dev: [B][iters] complex128 (re, im interleaved); fraction: host array [B].
+ * canvas x canvas float64 accumulation in the reference's order (sample index ascending per
+ * cell), so psf64_dev is bit-identical to the reference's float64 PSF.
+ *   center != 0: roll the weighted centroid to the canvas centre;
+ *   out_n: canvas, or 128 with canvas 256 for the [64:192] crop.
+ * psf64_dev: [B][out_n][out_n] float64 (may be NULL); psf16_dev: same shape, float16 converted
+ * as torch.HalfTensor(ndarray) does (float64 -> float32 -> float16; engine.py:84) (may be NULL).
+ * workspace_dev: dib_psf_rasterize_workspace_bytes(B, iters, canvas) bytes.
+ * ------------------------------------------------------------------------------------- */
+size_t dib_psf_rasterize_workspace_bytes(int B, int iters, int canvas);
+int dib_psf_rasterize(const double *traj_dev, int B, int iters, const double *fraction, int canvas,
+                      int center, int out_n, double *psf64_dev, void *psf16_dev,
+                      void *workspace_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIB_H_ */
