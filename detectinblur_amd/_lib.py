@@ -7,6 +7,11 @@ never imported from this package.
 import ctypes
 import os
 
+# torch must be imported BEFORE libdib_hip.so is opened: the wheel bundles its own HIP runtime
+# (same SONAME as /opt/rocm's); whichever is loaded first serves the whole process, and the
+# streams / device pointers we are handed belong to torch's.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 

@@ -41,6 +41,7 @@ template <int PQ_, int R_, int LROWS_> struct TileCfg {
   static constexpr int R = R_;          // rows per lane
   static constexpr int TH = 4 * R_;     // tile rows (4 waves)
   static constexpr int LROWS = LROWS_;  // LDS rows; band extent = LROWS - TH
+  static constexpr int U = (PQ_ + 63) / 64;  // 8-byte words a lane fills per LDS row
   static_assert(PQ_ * LROWS_ * 8 <= LDS_BYTES, "LDS budget");
 };
 using CfgA = TileCfg<96, 16, 96>;
@@ -82,7 +83,7 @@ template <typename Cfg, bool ZERO>
 __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch,
                                               int tx, int ty, uint2 *lds) {
 #pragma clang fp contract(off)
-  constexpr int PQ = Cfg::PQ, R = Cfg::R, TH = Cfg::TH, BAND = Cfg::LROWS - Cfg::TH;
+  constexpr int PQ = Cfg::PQ, R = Cfg::R, TH = Cfg::TH, BAND = Cfg::LROWS - Cfg::TH, U = Cfg::U;
   constexpr int G = 4;  // LDS rows a wave fills per batch of loads (8*G loads in flight per lane)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,11 +98,11 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
   __half *dst = reinterpret_cast<__half *>(d.out) + (size_t)ch * H * W;
 
   const int pqused = 64 + (cmax - cmin);  // words per LDS row actually used
-  // Byte offsets (within a source row) of the two words this lane fills per LDS row: once per tile.
-  unsigned coff[2][4];
-  unsigned cmask[2][2];  // zero-padding masks per packed pair (ZERO only)
+  // Byte offsets (within a source row) of the U words this lane fills per LDS row: once per tile.
+  unsigned coff[U][4];
+  unsigned cmask[U][2];  // zero-padding masks per packed pair (ZERO only)
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < U; ++u) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       bool z;
@@ -110,7 +111,6 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
       if (k & 1) cmask[u][k >> 1] |= m << 16; else cmask[u][k >> 1] = m;
     }
   }
-  const bool second = lane + 64 < pqused;
 
   h2 acc[R][2];
 #pragma unroll
@@ -128,7 +128,7 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
 
     // ---- fill: each wave takes G consecutive LDS rows per pass; row maps are scalar ------------
     for (int qb = wave * G; qb < nrows; qb += 4 * G) {
-      us2 v[G][2][2];
+      us2 v[G][U][2];
       bool zrow[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -137,7 +137,7 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
         // loads are unconditional (offsets are clamped in-bounds); only the LDS write is predicated,
         // so no wait lands inside a divergent block
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             v[g][u][k >> 1][k & 1] = *reinterpret_cast<const unsigned short *>(row + coff[u][k]);
@@ -146,8 +146,8 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
       for (int g = 0; g < G; ++g) {
         if (qb + g < nrows) {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (u == 0 || second) {
+          for (int u = 0; u < U; ++u) {
+            if (lane + 64 * u < pqused) {
               unsigned lo = __builtin_bit_cast(unsigned, v[g][u][0]), hi = __builtin_bit_cast(unsigned, v[g][u][1]);
               if (ZERO) {
                 lo &= cmask[u][0]; hi &= cmask[u][1];
@@ -212,12 +212,15 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
   for (int i = 0; i < R; ++i) {
     const int y = y0 + wave * R + i;
     if (y < H) {
-      __half *orow = dst + (size_t)y * W + x0 + lane;
+      unsigned short *orow = reinterpret_cast<unsigned short *>(dst) + (size_t)y * W + x0 + lane;
       const int xr = W - x0 - lane;  // columns remaining
-      if (xr > 0) orow[0] = __builtin_bit_cast(__half, acc[i][0][0]);
-      if (xr > 64) orow[64] = __builtin_bit_cast(__half, acc[i][0][1]);
-      if (xr > 128) orow[128] = __builtin_bit_cast(__half, acc[i][1][0]);
-      if (xr > 192) orow[192] = __builtin_bit_cast(__half, acc[i][1][1]);
+      // halves are extracted with integer ops: hipcc (ROCm 7.2) stored the LOW half twice when the
+      // high element of the fp16x2 accumulator was taken with a vector subscript
+      const unsigned a = __builtin_bit_cast(unsigned, acc[i][0]), b = __builtin_bit_cast(unsigned, acc[i][1]);
+      if (xr > 0) orow[0] = (unsigned short)(a & 0xffffu);
+      if (xr > 64) orow[64] = (unsigned short)(a >> 16);
+      if (xr > 128) orow[128] = (unsigned short)(b & 0xffffu);
+      if (xr > 192) orow[192] = (unsigned short)(b >> 16);
     }
   }
 }
