@@ -40,10 +40,24 @@ class TapTables:
         """(ntaps, rmin, rmax, cmin, cmax) -- a D2H copy; for tests and debugging only."""
         return self.buf[i * self.words:i * self.words + 5].tolist()
 
+    def segments(self, i):
+        """[(first_tap, end_tap, r_first, r_last, cmin, cmax)] of table i -- tests only."""
+        nseg = int(self.buf[i * self.words + 7].item())
+        off = i * self.words + ((8 + self.K + 1 + 3) & ~3) + 2 * self.K * self.K
+        t = self.buf[off:off + 4 * nseg].cpu().view(-1, 4).tolist()
+        return [(a, b, c >> 8, c & 255, d >> 8, d & 255) for a, b, c, d in t]
+
+    def ltaps(self, i):
+        """per-tap (lds_byte_offset, weight_bits) of table i -- tests only."""
+        n = self.header(i)[0]
+        off = i * self.words + ((8 + self.K + 1 + 3) & ~3) + 6 * self.K * self.K
+        t = self.buf[off:off + n].cpu()
+        return t & 0xffff, (t >> 16) & 0xffff
+
     def taps(self, i):
         """(rows, cols, weight_bits) of table i as CPU tensors -- tests only."""
         h = self.header(i)
-        off = i * self.words + ((8 + self.K + 1 + 1) & ~1)
+        off = i * self.words + ((8 + self.K + 1 + 3) & ~3)
         t = self.buf[off:off + 2 * h[0]].cpu().view(-1, 2)
         rc = t[:, 0]
         return (rc >> 8) & 0xff, rc & 0xff, t[:, 1]
@@ -106,6 +120,11 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
 # tensors (reference engine.py:101-105); the second call reuses the tables of the first instead
 # of re-running normalise + nonzero as the reference does (utils.py:372-374).
 _cache = {"key": None, "tables": None}
+
+
+def invalidate_cache():
+    _cache["key"] = _cache["tables"] = None
+    _cache.pop("pin", None)
 
 
 def compact_psfs_cached(psfs, normalize):

@@ -10,16 +10,20 @@
 // which is bit-identical to the reference's Half tensors.
 //
 // Tiled fp16 kernel -- memory layout in LDS ("split-column" layout):
-//   A workgroup (4 waves) owns a 256-wide output tile of ONE channel.  Lane l of every wave owns
+//   A workgroup (4 waves) owns a 256 x 32 output tile of ONE channel.  Lane l of every wave owns
 //   the four columns x0 + l + 64k (k = 0..3), packed as two fp16x2 registers per row.  LDS row q
 //   holds the source window row as 8-byte words:  word j = { P[j], P[j+64], P[j+128], P[j+192] },
 //   j in [0, 64+ex), where P is the (virtually padded) source row starting at column
-//   x0 + pb - cmax and ex = cmax - cmin is the PSF's column extent.  A tap (r, c) is then ONE
-//   aligned, bank-conflict-free ds_read_b64 at word  lane + (cmax - c)  for ANY column shift --
-//   odd shifts included, which a plain row-major fp16 layout cannot do with aligned packed reads.
-//   Row shifts are LDS row offsets; the R rows a lane owns use compile-time immediate offsets, so
-//   a tap costs one v_add (address) + R x { ds_read_b64, 2 v_pk_mul_f16, 2 v_pk_add_f16 }.
-//   PSF rows are processed in bands of at most (LDS rows - tile rows) so any row extent fits.
+//   x0 + pb - cmax and ex = cmax - cmin is the column extent of the tap SEGMENT being processed.
+//   A tap (r, c) is then ONE aligned, bank-conflict-free ds_read_b64 at word  lane + (cmax - c)
+//   for ANY column shift -- odd shifts included, which a plain row-major fp16 layout cannot do
+//   with aligned packed reads.  Row shifts are LDS row offsets; the R rows a lane owns use
+//   compile-time immediate offsets, so a tap costs one v_add (address) +
+//   R x { ds_read_b64, 2 v_pk_mul_f16, 2 v_pk_add_f16 }.
+//   The tap list arrives cut into segments (dib_compact.hip) whose bounding box is at most
+//   17 PSF rows x 33 PSF columns, so ONE small LDS window (48 rows x 96 words = 36 KB, four
+//   workgroups per CU) serves any PSF; a wide or tall PSF simply takes several fill+accumulate
+//   rounds, in tap order, with the accumulators staying in registers.
 //
 // Roofline: HBM-bound by design (12.8 MB algorithmic bytes per 3x800x1333 image); per tap-pixel
 // the kernel spends 1/4 LDS read + 1 packed VALU op, which balances HBM time at ~35-50 taps.
@@ -29,227 +33,417 @@
 namespace dib {
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int TILE_W = 256;
-constexpr int LDS_BYTES = 96 * 96 * 8;  // 73,728 B: two workgroups per CU
+constexpr int PQ = WIN_PITCH;        // LDS row pitch in 8-byte words (96)
+constexpr int R = 8;                // rows per lane
+constexpr int NW = 4;               // waves per workgroup
+constexpr int TH = NW * R;          // tile rows (32)
+constexpr int LROWS = TH + SEG_ROWS;  // LDS rows per window (48)
+constexpr int WIN_WORDS = LROWS * PQ;
+constexpr int LDS_BYTES = 2 * WIN_WORDS * 8;  // two windows (double buffer): 73,728 B, 2 workgroups per CU
+constexpr int G = (LROWS + NW - 1) / NW;  // LDS rows a wave fills: all of them in ONE batch of loads (12)
+constexpr int WG_PER_CU = 2;
 
-// Class A: column extent <= 32 (low exposure, the training default): 64-row tiles.
-// Class B: column extent <= 128 (everything a 128-wide PSF can hold): 32-row tiles.
-template <int PQ_, int R_, int LROWS_> struct TileCfg {
-  static constexpr int PQ = PQ_;        // LDS row pitch in 8-byte words (>= 64 + ex)
-  static constexpr int R = R_;          // rows per lane
-  static constexpr int TH = 4 * R_;     // tile rows (4 waves)
-  static constexpr int LROWS = LROWS_;  // LDS rows; band extent = LROWS - TH
-  static constexpr int U = (PQ_ + 63) / 64;  // 8-byte words a lane fills per LDS row
-  static_assert(PQ_ * LROWS_ * 8 <= LDS_BYTES, "LDS budget");
-};
-using CfgA = TileCfg<96, 16, 96>;
-using CfgB = TileCfg<192, 8, 48>;
-
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // 64-bit asm operands must be scalar integers: hipcc (ROCm 7.2) aliases both lanes of a
 // 2 x 32-bit vector operand of an inline-asm "=v" output to the same register.
 typedef unsigned long long u2;
 
-// ---- LDS reads of the tap loop, hand-issued -------------------------------------------------
-// hipcc merges neighbouring 8-byte LDS reads into ds_read2_b64 (half the LDS rate of ds_read_b64
-// on gfx950, MI355X_MICROARCH.md LDS table) and waits right behind each one.  The reads are
-// therefore issued as plain ds_read_b64 with immediate row offsets from inline asm, one tap
-// ahead of the arithmetic, and waited for with an explicit lgkmcnt(0) that carries the
-// destination registers as in/out operands so no consumer can be scheduled above it.
-template <int OFF> __device__ __forceinline__ void lds_rd64(u2 &dst, unsigned addr) {
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+// ---- the tap loop's memory side, hand-issued ---------------------------------------------------
+// Left to hipcc, the tap loop serialises: it merges the 8-byte LDS reads into ds_read2_b64 (half
+// the LDS rate of ds_read_b64 on gfx950), sinks the scalar tap load down to its first use and waits
+// right behind every access.  One inline-asm block per tap therefore does the whole memory side:
+//     s_waitcnt lgkmcnt(0)        data of tap t (issued one block ago) and ltap t+1 have arrived
+//     A = B ; B = C               rotate the scalar tap words inside the asm, after the wait
+//     8 x ds_read_b64             data of tap t+1, immediate row offsets, into the OTHER buffer
+//     s_load_dword C              ltap t+2
+// and the 32 packed multiply/adds of tap t follow in C++ while those accesses are in flight.  The
+// buffer of tap t and the tap words are in/out operands of the block, so nothing that consumes them
+// can be scheduled above the wait.  lgkmcnt is shared by LDS and SMEM, vmcnt is never touched: it
+// belongs to the window loads of the NEXT item, in flight across the whole loop.
+static_assert(WIN_PITCH * 8 == 768, "the asm below hard-codes the LDS row pitch");
+
+// Operands: %0-%7 destination buffer, %8 A, %9 B, %10 C, %11 byte offset of the next ltap to load,
+// %12 scalar temp, %13 LDS address, %14 ltaps base, %15 this lane's base address in the window.
+#define DIB_TAP_OPERANDS(buf)                                                                              \
+  "=&v"(buf[0]), "=&v"(buf[1]), "=&v"(buf[2]), "=&v"(buf[3]), "=&v"(buf[4]), "=&v"(buf[5]), "=&v"(buf[6]),  \
+      "=&v"(buf[7]), "+s"(A), "+s"(B), "+s"(C), "+s"(toff), "=&s"(stmp), "=&v"(vaddr)
+#define DIB_RD8                                                                                            \
+  "ds_read_b64 %0, %13 offset:0\n\tds_read_b64 %1, %13 offset:768\n\tds_read_b64 %2, %13 offset:1536\n\t"   \
+  "ds_read_b64 %3, %13 offset:2304\n\tds_read_b64 %4, %13 offset:3072\n\tds_read_b64 %5, %13 offset:3840\n\t" \
+  "ds_read_b64 %6, %13 offset:4608\n\tds_read_b64 %7, %13 offset:5376\n\t"
+
+// first block of a segment: fetch ltaps t0 and t0+1, issue the reads of tap t0, start loading t0+2
+__device__ __forceinline__ void tap_first(u2 (&buf)[R], unsigned &A, unsigned &B, unsigned &C, unsigned &toff,
+                                          unsigned long long ltaps, unsigned lane_addr) {
+  unsigned stmp, vaddr;
+  asm volatile(
+      "s_load_dword %9, %14, %11\n\t"
+      "s_add_u32 %11, %11, 4\n\t"
+      "s_load_dword %10, %14, %11\n\t"
+      "s_add_u32 %11, %11, 4\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_and_b32 %12, %9, 0xffff\n\t"
+      "v_add_u32 %13, %12, %15\n\t" DIB_RD8
+      : DIB_TAP_OPERANDS(buf)
+      : "s"(ltaps), "v"(lane_addr)
+      : "scc");
 }
-template <int PITCH_BYTES, int R, int I = 0> __device__ __forceinline__ void lds_rd_rows(u2 (&buf)[R], unsigned addr) {
-  if constexpr (I < R) {
-    lds_rd64<I * PITCH_BYTES>(buf[I], addr);
-    lds_rd_rows<PITCH_BYTES, R, I + 1>(buf, addr);
+// steady state: data of the previous block and ltap C have arrived; rotate A<-B<-C; issue the
+// reads of the new B into `buf`; start loading the following ltap into C
+__device__ __forceinline__ void tap_next(u2 (&buf)[R], unsigned &A, unsigned &B, unsigned &C, unsigned &toff,
+                                         unsigned long long ltaps, unsigned lane_addr) {
+  unsigned stmp, vaddr;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 %8, %9\n\t"
+      "s_mov_b32 %9, %10\n\t"
+      "s_and_b32 %12, %9, 0xffff\n\t"
+      "v_add_u32 %13, %12, %15\n\t" DIB_RD8
+      "s_load_dword %10, %14, %11\n\t"
+      "s_add_u32 %11, %11, 4"
+      : DIB_TAP_OPERANDS(buf)
+      : "s"(ltaps), "v"(lane_addr)
+      : "scc");
+  // inline-asm results count as divergent in hipcc's uniformity analysis; carried around the loop
+  // they would land in VGPRs and could not feed the next block's "s" operands
+  A = __builtin_amdgcn_readfirstlane(A); B = __builtin_amdgcn_readfirstlane(B);
+  C = __builtin_amdgcn_readfirstlane(C); toff = __builtin_amdgcn_readfirstlane(toff);
+}
+// last tap of a segment: nothing left to issue
+__device__ __forceinline__ void tap_last(unsigned &A, unsigned &B) {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, %1" : "+s"(A), "+s"(B));
+}
+// Ordering of the arithmetic: every v_pk_mul_f16 of tap t takes its weight from A, and A is an
+// output of the block that holds the wait for tap t's data -- so no multiply can be scheduled
+// above that wait, and the data buffers need no (copy-inducing) pass-through operands.
+
+// Diagnostic stamps (nullptr in every product launch): shader-clock readings of lane 0 of wave 0.
+__device__ __forceinline__ void stamp(unsigned long long *dbg, int slot) {
+  if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+}
+
+// One work item = one (tile, tap segment): a window of source rows to stage and a run of taps.
+// Kept to 8 packed words: three items are live at once (being accumulated, being staged, being
+// decoded) and they must all stay in SGPRs.
+struct Item {
+  int H, W;
+  int tab_off;   // word offset of the image's tap table inside `tables`
+  int where;     // img | ch << 8 | mode << 16 | first << 24 | last << 25 | valid << 26
+  int xy;        // x0 | y0 << 16
+  int seg;       // rl | cmax << 8 | nrows << 16 | pqused << 24
+  int t0, t1;
+
+  __device__ int img() const { return where & 255; }
+  __device__ int ch() const { return (where >> 8) & 255; }
+  __device__ int mode() const { return (where >> 16) & 255; }
+  __device__ bool first() const { return (where >> 24) & 1; }
+  __device__ bool last() const { return (where >> 25) & 1; }
+  __device__ bool valid() const { return (where >> 26) & 1; }
+  __device__ int x0() const { return xy & 0xffff; }
+  __device__ int y0() const { return (unsigned)xy >> 16; }
+  __device__ int rl() const { return seg & 255; }
+  __device__ int cmax() const { return (seg >> 8) & 255; }
+  __device__ int nrows() const { return (seg >> 16) & 255; }
+  __device__ int pqused() const { return (unsigned)seg >> 24; }
+};
+
+// n / d for 0 <= n < 2^24 with rcp = 1.0f / d: one multiply and a one-step correction instead of
+// the ~40-instruction integer-division expansion
+__device__ __forceinline__ int fast_div(int n, int d, float rcp) {
+  int q = (int)((float)n * rcp);
+  const int r = n - q * d;
+  if (r >= d) ++q;
+  else if (r < 0) --q;
+  return q;
+}
+
+// Walks the (tile, segment) items of this workgroup: tiles wg, wg + nwg, ... of the flattened
+// [image][channel][ty][tx] list (a stride of nwg mixes all images into every workgroup, which
+// balances PSFs of different tap counts), segments in order inside each tile.  Tiles only move
+// forward, so the image lookup is a cursor that advances, not a search.
+struct ItemWalker {
+  const BlurBatch &batch;
+  const int *tables;
+  int K, tile, stride, seg, nsegs;
+  int img, img_begin, img_end;  // image cursor: tiles [img_begin, img_end) belong to batch.img[img]
+  int tiles_x, per_ch;
+  float rcp_tx, rcp_pc;
+  const uint4 *segs;
+  Item cur;
+
+  __device__ ItemWalker(const BlurBatch &b, const int *t, int K_, int first_tile, int stride_)
+      : batch(b), tables(t), K(K_), tile(first_tile), stride(stride_), seg(0), nsegs(0), img(-1), img_begin(0), img_end(0),
+        tiles_x(1), per_ch(1), rcp_tx(1.f), rcp_pc(1.f), segs(nullptr) {
+    cur.where = 0;
+    open_tile();
   }
+  __device__ void open_tile() {
+    if (tile >= batch.total_tiles) { cur.where = 0; return; }
+    while (tile >= img_end) {  // enter the next image (uniform; at most batch.n times per workgroup)
+      ++img;
+      const ImageDesc &d = batch.img[img];
+      img_begin = d.tile_begin;
+      tiles_x = d.tiles_x;
+      per_ch = d.tiles_x * d.tiles_y;
+      img_end = img_begin + d.C * per_ch;
+      rcp_tx = 1.0f / (float)tiles_x;
+      rcp_pc = 1.0f / (float)per_ch;
+      const int *tab = tables + (size_t)d.table * table_words(K);
+      nsegs = tab[HDR_NSEGS];
+      segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
+      cur.H = d.H; cur.W = d.W;
+      cur.tab_off = d.table * table_words(K);
+    }
+    int local = tile - img_begin;
+    const int ch = fast_div(local, per_ch, rcp_pc);
+    local -= ch * per_ch;
+    const int ty = fast_div(local, tiles_x, rcp_tx), tx = local - ty * tiles_x;
+    cur.where = img | (ch << 8) | (pad_mode_for(K, cur.H, cur.W) << 16) | (1 << 26);
+    cur.xy = (tx * TILE_W) | ((ty * TH) << 16);
+    seg = 0;
+    load_seg();
+  }
+  __device__ void load_seg() {
+    cur.where &= ~(3 << 24);
+    if (seg == 0) cur.where |= 1 << 24;
+    if (nsegs == 0) {  // no taps at all: the tile is written as zeros
+      cur.t0 = cur.t1 = 0; cur.seg = 0; cur.where |= 1 << 25;
+      return;
+    }
+    const uint4 sg = segs[seg];
+    cur.t0 = sg.x; cur.t1 = sg.y;
+    const int rf = sg.z >> 8, rl = sg.z & 255, cmin = sg.w >> 8, cmax = sg.w & 255;
+    cur.seg = rl | (cmax << 8) | ((TH + (rl - rf)) << 16) | ((64 + (cmax - cmin)) << 24);
+    if (seg + 1 >= nsegs) cur.where |= 1 << 25;
+  }
+  __device__ void advance() {
+    if (!cur.valid()) return;
+    if (seg + 1 < nsegs) { ++seg; load_seg(); }
+    else { tile += stride; open_tile(); }
+  }
+};
+
+// The walker's values are wave-uniform by construction (they derive from blockIdx and kernel
+// arguments), but after the struct has travelled through the software-pipelined loop hipcc no
+// longer proves it and falls back to per-lane loads for the tap list.  v_readfirstlane pins every
+// field to an SGPR again: taps come in through scalar loads and never touch vmcnt, which must
+// stay reserved for the window loads that are in flight across the arithmetic.  Items carry
+// integer handles only; pointers are re-derived from the kernel arguments so that they keep
+// their global address space (a pointer rebuilt from integers degrades to flat loads).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ Item uniform_item(const Item &a) {
+  Item b;
+  b.H = uni(a.H); b.W = uni(a.W); b.tab_off = uni(a.tab_off); b.where = uni(a.where);
+  b.xy = uni(a.xy); b.seg = uni(a.seg); b.t0 = uni(a.t0); b.t1 = uni(a.t1);
+  return b;
 }
-template <int R> __device__ __forceinline__ void lds_wait(u2 (&b)[R]) {
-  static_assert(R == 8 || R == 16, "R");
-  if constexpr (R == 16) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
-    asm volatile("" : "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]), "+v"(b[14]), "+v"(b[15]));
+
+// Raw source values of one window as they come back from memory: per LDS row the five fp16
+// values P[lane + 64k], k = 0..4 (word j and word j+64 of the split layout share three of them).
+struct FillRegs {
+  unsigned short v[G][5];
+  unsigned zmask;  // bit k: column k is zero padding; bit 8+g: row g is zero padding (PAD_ZERO only)
+};
+
+// Wave-uniform buffer descriptor of one channel plane (base, byte size): loads and stores then take
+// a 32-bit per-lane byte offset (voffset) plus a scalar row offset (soffset) -- no 64-bit address
+// arithmetic on the vector ALU, which the arithmetic of the co-resident wave keeps busy.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *img_base, int ch, int H, int W) {
+  const unsigned long long a = (unsigned long long)img_base + (unsigned long long)ch * H * W * 2ull;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, H * W * 2, 0x00020000);
+}
+
+__device__ __forceinline__ void issue_fill(const BlurBatch &batch, int K, const Item &it, FillRegs &f, int wave, int lane) {
+  const int pb = K / 2 - 1, pa = K / 2, mode = it.mode();
+  const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(batch.img[it.img()].in, it.ch(), it.H, it.W);
+  unsigned coff[5];
+  f.zmask = 0;
+  const int c_first = it.x0() + pb - it.cmax();  // virtual column of P[0]
+  if (c_first >= 0 && c_first + 63 + 256 <= it.W - 1) {
+    // interior tile: no reflection, no clamping
+#pragma unroll
+    for (int k = 0; k < 5; ++k) coff[k] = 2u * (unsigned)(c_first + lane + 64 * k);
   } else {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      bool z;
+      coff[k] = 2u * (unsigned)map_coord(c_first + lane + 64 * k, it.W, pa, pb, mode, z);
+      if (z) f.zmask |= 1u << k;
+    }
+  }
+  const int qb = wave * G, r_first = it.y0() + pb - it.rl() + qb;  // virtual row of this wave's first LDS row
+  const int w2 = it.W * 2;
+  if (r_first >= 0 && r_first + G - 1 <= it.H - 1) {
+    // every row of the batch lies inside the image (rows past the window's end are loaded but never
+    // written to LDS); unconditional loads, all G*5 in flight before any is used
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int soff = (r_first + g) * w2;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) f.v[g][k] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, coff[k], soff, 0);
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      bool zr;
+      const int sr = map_coord(r_first - qb + min(qb + g, max(it.nrows() - 1, 0)), it.H, pa, pb, mode, zr);
+      if (zr) f.zmask |= 1u << (8 + g);
+      const int soff = __builtin_amdgcn_readfirstlane(sr * w2);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) f.v[g][k] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, coff[k], soff, 0);
+    }
   }
 }
 
-template <typename Cfg, bool ZERO>
-__device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch,
-                                              int tx, int ty, uint2 *lds) {
+template <bool ZERO>
+__device__ __forceinline__ void commit_fill(const Item &it, const FillRegs &f, uint2 *win, int wave, int lane) {
+  const int qb = wave * G, nrows = it.nrows();
+  const bool second = lane + 64 < it.pqused();
+  uint2 *wp = win + qb * PQ + lane;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (qb + g < nrows) {  // wave-uniform
+      unsigned c[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        c[k] = f.v[g][k];
+        if (ZERO && (((f.zmask >> k) & 1u) || ((f.zmask >> (8 + g)) & 1u))) c[k] = 0;
+      }
+      wp[g * PQ] = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+      if (second) wp[g * PQ + 64] = make_uint2(c[1] | (c[2] << 16), c[3] | (c[4] << 16));
+    }
+  }
+}
+
+// taps t0..t1 of the item in row-major order; memory side in the asm blocks above
+__device__ __forceinline__ void accumulate(const int *__restrict__ tables, int K, const Item &it, h2 (&acc)[R][2], unsigned lane_addr) {
 #pragma clang fp contract(off)
-  constexpr int PQ = Cfg::PQ, R = Cfg::R, TH = Cfg::TH, BAND = Cfg::LROWS - Cfg::TH, U = Cfg::U;
-  constexpr int G = 4;  // LDS rows a wave fills per batch of loads (8*G loads in flight per lane)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = d.H, W = d.W;
-  const int pb = K / 2 - 1, pa = K / 2;
-  const int mode = ZERO ? PAD_ZERO : (K > 129 ? PAD_REPLICATE : PAD_REFLECT);
-  const int rmin = tab[HDR_RMIN], rmax = tab[HDR_RMAX], cmin = tab[HDR_CMIN], cmax = tab[HDR_CMAX];
-  const int *rowptr = tab + table_rowptr_off();
-  const uint2 *taps = reinterpret_cast<const uint2 *>(tab + table_taps_off(K));
-  const int x0 = tx * TILE_W, y0 = ty * TH;
-  const char *src = reinterpret_cast<const char *>(d.in) + (size_t)ch * H * W * 2;
-  __half *dst = reinterpret_cast<__half *>(d.out) + (size_t)ch * H * W;
-
-  const int pqused = 64 + (cmax - cmin);  // words per LDS row actually used
-  // Byte offsets (within a source row) of the U words this lane fills per LDS row: once per tile.
-  unsigned coff[U][4];
-  unsigned cmask[U][2];  // zero-padding masks per packed pair (ZERO only)
+  const int n = __builtin_amdgcn_readfirstlane(it.t1 - it.t0);
+  if (n <= 0) return;
+  // asm "s" operands must be provably uniform: rebuild the (integer) address from v_readfirstlane halves
+  const unsigned long long la = (unsigned long long)(tables + it.tab_off + table_ltaps_off(K));
+  const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
+  u2 bx[R], by[R];
+  unsigned A = 0, B = 0, C = 0, toff = (unsigned)__builtin_amdgcn_readfirstlane(it.t0 * 4);
+  auto madd = [&](u2(&buf)[R], unsigned tapw) {
+    const unsigned wb = tapw >> 16;
+    const h2 w = __builtin_bit_cast(h2, wb | (wb << 16));
+    // all products first, then all sums: independent packed ops back to back (no RAW stalls)
+    h2 p0[R], p1[R];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      bool z;
-      coff[u][k] = 2u * (unsigned)map_coord(x0 + pb - cmax + lane + 64 * u + 64 * k, W, pa, pb, mode, z);
-      unsigned m = z ? 0u : 0xffffu;
-      if (k & 1) cmask[u][k >> 1] |= m << 16; else cmask[u][k >> 1] = m;
+    for (int i = 0; i < R; ++i) {
+      p0[i] = __builtin_bit_cast(h2, (unsigned)buf[i]) * w;
+      p1[i] = __builtin_bit_cast(h2, (unsigned)(buf[i] >> 32)) * w;
     }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      acc[i][0] = acc[i][0] + p0[i];
+      acc[i][1] = acc[i][1] + p1[i];
+    }
+  };
+  tap_first(bx, A, B, C, toff, ltaps, lane_addr);
+  int i = 0;
+  while (true) {
+    if (i == n - 1) { tap_last(A, B); madd(bx, A); break; }
+    tap_next(by, A, B, C, toff, ltaps, lane_addr);
+    madd(bx, A);
+    ++i;
+    if (i == n - 1) { tap_last(A, B); madd(by, A); break; }
+    tap_next(bx, A, B, C, toff, ltaps, lane_addr);
+    madd(by, A);
+    ++i;
   }
+}
 
-  h2 acc[R][2];
-#pragma unroll
-  for (int i = 0; i < R; ++i) { acc[i][0] = h2{0, 0}; acc[i][1] = h2{0, 0}; }
-
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
-  const unsigned lane_addr = lds0 + (unsigned)((wave * R) * PQ + lane) * 8u;
-
-  for (int rb = rmin; rb <= rmax;) {
-    const int re = min(rmax, rb + BAND);  // band of PSF rows [rb, re]
-    const int t0 = rowptr[rb], t1 = rowptr[re + 1];
-    if (t0 == t1) { rb = re + 1; continue; }  // (uniform) empty band
-    const int nrows = TH + (re - rb);
-    const int s_top = y0 + pb - re;  // virtual source row held in LDS row 0
-
-    // ---- fill: each wave takes G consecutive LDS rows per pass; row maps are scalar ------------
-    for (int qb = wave * G; qb < nrows; qb += 4 * G) {
-      us2 v[G][U][2];
-      bool zrow[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        int sr = map_coord(s_top + min(qb + g, nrows - 1), H, pa, pb, mode, zrow[g]);
-        const char *row = src + (size_t)sr * W * 2;
-        // loads are unconditional (offsets are clamped in-bounds); only the LDS write is predicated,
-        // so no wait lands inside a divergent block
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            v[g][u][k >> 1][k & 1] = *reinterpret_cast<const unsigned short *>(row + coff[u][k]);
-      }
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (qb + g < nrows) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (lane + 64 * u < pqused) {
-              unsigned lo = __builtin_bit_cast(unsigned, v[g][u][0]), hi = __builtin_bit_cast(unsigned, v[g][u][1]);
-              if (ZERO) {
-                lo &= cmask[u][0]; hi &= cmask[u][1];
-                if (zrow[g]) { lo = 0; hi = 0; }
-              }
-              lds[(qb + g) * PQ + lane + 64 * u] = make_uint2(lo, hi);
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- accumulate: taps t0..t1 in row-major order, scalar-broadcast, LDS reads one tap ahead ----
-    {
-      u2 bx[R], by[R];
-      auto issue = [&](u2(&buf)[R], uint2 tp) {
-        const int r = tp.x >> 8, c = tp.x & 255;
-        lds_rd_rows<PQ * 8, R>(buf, lane_addr + (unsigned)(((re - r) * PQ + (cmax - c)) * 8));
-      };
-      auto madd = [&](u2(&buf)[R], uint2 tp) {
-        const unsigned wb = tp.y & 0xffffu;
-        const h2 w = __builtin_bit_cast(h2, wb | (wb << 16));
-        // all products first, then all sums: independent packed ops back to back (no RAW stalls)
-        h2 p0[R], p1[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-          p0[i] = __builtin_bit_cast(h2, (unsigned)buf[i]) * w;
-          p1[i] = __builtin_bit_cast(h2, (unsigned)(buf[i] >> 32)) * w;
-        }
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-          acc[i][0] = acc[i][0] + p0[i];
-          acc[i][1] = acc[i][1] + p1[i];
-        }
-      };
-      int t = t0;
-      uint2 ta = taps[t], tb = ta;
-      issue(bx, ta);
-      while (true) {
-        const bool has_b = t + 1 < t1;
-        if (has_b) tb = taps[t + 1];
-        lds_wait<R>(bx);
-        if (has_b) issue(by, tb);
-        madd(bx, ta);
-        if (!has_b) break;
-        const bool has_a = t + 2 < t1;
-        if (has_a) ta = taps[t + 2];
-        lds_wait<R>(by);
-        if (has_a) issue(bx, ta);
-        madd(by, tb);
-        if (!has_a) break;
-        t += 2;
-      }
-    }
-    __syncthreads();
-    rb = re + 1;
-  }
-
-  // ---- store: lane owns columns x0 + lane + 64k ------------------------------------------------
+__device__ __forceinline__ void store_tile(const BlurBatch &batch, const Item &it, const h2 (&acc)[R][2], int wave, int lane) {
+  const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(batch.img[it.img()].out, it.ch(), it.H, it.W);
+  const int xr = it.W - it.x0() - lane;  // columns remaining for this lane
+  const unsigned voff = 2u * (unsigned)(it.x0() + lane);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int y = y0 + wave * R + i;
-    if (y < H) {
-      unsigned short *orow = reinterpret_cast<unsigned short *>(dst) + (size_t)y * W + x0 + lane;
-      const int xr = W - x0 - lane;  // columns remaining
+    const int y = it.y0() + wave * R + i;
+    if (y < it.H) {  // wave-uniform
+      const int soff = y * it.W * 2;
       // halves are extracted with integer ops: hipcc (ROCm 7.2) stored the LOW half twice when the
       // high element of the fp16x2 accumulator was taken with a vector subscript
       const unsigned a = __builtin_bit_cast(unsigned, acc[i][0]), b = __builtin_bit_cast(unsigned, acc[i][1]);
-      if (xr > 0) orow[0] = (unsigned short)(a & 0xffffu);
-      if (xr > 64) orow[64] = (unsigned short)(a >> 16);
-      if (xr > 128) orow[128] = (unsigned short)(b & 0xffffu);
-      if (xr > 192) orow[192] = (unsigned short)(b >> 16);
+      if (xr > 0) __builtin_amdgcn_raw_buffer_store_b16((short)(a & 0xffffu), rsrc, voff, soff, 0);
+      if (xr > 64) __builtin_amdgcn_raw_buffer_store_b16((short)(a >> 16), rsrc, voff + 128u, soff, 0);
+      if (xr > 128) __builtin_amdgcn_raw_buffer_store_b16((short)(b & 0xffffu), rsrc, voff + 256u, soff, 0);
+      if (xr > 192) __builtin_amdgcn_raw_buffer_store_b16((short)(b >> 16), rsrc, voff + 384u, soff, 0);
     }
   }
 }
 
-// Grid: one workgroup per (image, channel, 256x32 tile slot).  Images whose PSF falls in the
-// 64-row class use every other slot; the others exit at once.  Images whose column extent exceeds
-// 128 (only possible with a 256-wide PSF) are left to blur_generic_kernel.
-__global__ __launch_bounds__(256, 2) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables,
-                                                                int K) {
+// Persistent kernel: WG_PER_CU workgroups per CU, each walking its own list of (tile, segment)
+// items.  Software pipeline, one barrier per item: while item n is accumulated out of LDS window
+// n%2, the global loads of item n+1 are in flight in registers; they are packed into window
+// (n+1)%2 once the arithmetic of item n has been issued.  A window is only rewritten two items
+// after it was last read, and every wave passes the barrier in between.
+__global__ __launch_bounds__(256, WG_PER_CU) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables,
+                                                                        int K, unsigned long long *dbg) {
   extern __shared__ uint2 lds[];
-  int b = blockIdx.x, i = 0;
-  while (i + 1 < batch.n && b >= batch.img[i + 1].tile_begin) ++i;
-  const ImageDesc &d = batch.img[i];
-  int local = b - d.tile_begin;
-  const int per_ch = d.tiles_x * d.tiles_y32;
-  const int ch = local / per_ch;
-  local -= ch * per_ch;
-  const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
-  const int *tab = tables + (size_t)d.table * table_words(K);
-  const int ex = tab[HDR_CMAX] - tab[HDR_CMIN];
-  // ntaps == 0 gives ex < 0: class A with an empty tap loop writes the zeros the reference returns
-  const bool zero = pad_mode_for(K, d.H, d.W) == PAD_ZERO;
-  if (ex <= CfgA::PQ - 64) {
-    if (ty * CfgA::TH >= d.H) return;  // unused slot of the 64-row class
-    if (zero) blur_tile_f16<CfgA, true>(d, tab, K, ch, tx, ty, lds);
-    else blur_tile_f16<CfgA, false>(d, tab, K, ch, tx, ty, lds);
-  } else if (ex <= CfgB::PQ - 64) {
-    if (zero) blur_tile_f16<CfgB, true>(d, tab, K, ch, tx, ty, lds);
-    else blur_tile_f16<CfgB, false>(d, tab, K, ch, tx, ty, lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ItemWalker walk(batch, tables, K, blockIdx.x, gridDim.x);
+  if (!walk.cur.valid()) return;
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+  const unsigned lane_off = (unsigned)((wave * R) * PQ + lane) * 8u;
+  h2 acc[R][2];
+  FillRegs regs;
+
+  stamp(dbg, 0);
+  Item it = uniform_item(walk.cur);
+  issue_fill(batch, K, it, regs, wave, lane);
+  walk.advance();
+  Item nxt = uniform_item(walk.cur);
+  if (it.mode() == PAD_ZERO) commit_fill<true>(it, regs, lds, wave, lane);
+  else commit_fill<false>(it, regs, lds, wave, lane);
+  __syncthreads();
+  stamp(dbg, 1);
+  int par = 0, nitems = 0;
+  unsigned long long c_walk = 0, c_issue = 0, c_acc = 0, c_store = 0, c_commit = 0, c_bar = 0, tq = 0;
+#define DIB_TICK(var) do { if (dbg) { unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - tq; tq = now_; } } while (0)
+  if (dbg) tq = __builtin_readcyclecounter();
+  while (true) {
+    if (nxt.valid()) issue_fill(batch, K, nxt, regs, wave, lane);   // loads fly during the arithmetic below
+    DIB_TICK(c_issue);
+    // decode the item after next now: its scalar loads complete under the arithmetic as well
+    walk.advance();
+    const Item nxt2 = uniform_item(walk.cur);
+    DIB_TICK(c_walk);
+    if (it.first()) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) { acc[i][0] = h2{0, 0}; acc[i][1] = h2{0, 0}; }
+    }
+    accumulate(tables, K, it, acc, lds0 + (unsigned)par * (WIN_WORDS * 8) + lane_off);
+    DIB_TICK(c_acc);
+    if (it.last()) store_tile(batch, it, acc, wave, lane);
+    DIB_TICK(c_store);
+    ++nitems;
+    if (!nxt.valid()) break;
+    par ^= 1;
+    if (nxt.mode() == PAD_ZERO) commit_fill<true>(nxt, regs, lds + par * WIN_WORDS, wave, lane);
+    else commit_fill<false>(nxt, regs, lds + par * WIN_WORDS, wave, lane);
+    DIB_TICK(c_commit);
+    __syncthreads();
+    DIB_TICK(c_bar);
+    it = nxt;
+    nxt = nxt2;
+  }
+  if (dbg && threadIdx.x == 0) {
+    dbg[(size_t)blockIdx.x * 8 + 4] = (c_issue << 32) | (c_acc & 0xffffffffull);
+    dbg[(size_t)blockIdx.x * 8 + 5] = (c_store << 32) | (c_commit & 0xffffffffull);
+    dbg[(size_t)blockIdx.x * 8 + 6] = (c_walk << 32) | (c_bar & 0xffffffffull);
+  }
+  stamp(dbg, 2);
+  if (dbg && threadIdx.x == 0) {
+    dbg[(size_t)blockIdx.x * 8 + 3] = (unsigned long long)nitems;
+    dbg[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
   }
 }
 
@@ -276,7 +470,6 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(BlurBatch batch, cons
   while (i + 1 < batch.n && b >= batch.img[i + 1].tile_begin) ++i;
   const ImageDesc &d = batch.img[i];
   const int *tab = tables + (size_t)d.table * table_words(K);
-  if (ONLY_WIDE && tab[HDR_CMAX] - tab[HDR_CMIN] <= CfgB::PQ - 64) return;
   const int H = d.H, W = d.W, pb = K / 2 - 1, pa = K / 2, mode = pad_mode_for(K, H, W);
   const long long n = (long long)d.C * H * W;
   const long long e = (long long)(b - d.tile_begin) * 256 + threadIdx.x;
@@ -303,6 +496,10 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(BlurBatch batch, cons
 
 using namespace dib;
 
+// Diagnostics only: when set, the tiled kernel records per-workgroup phase stamps (8 x u64 each).
+static unsigned long long *g_stamp_buffer = nullptr;
+extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) { g_stamp_buffer = (unsigned long long *)dev_ptr; }
+
 extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, const int *C, const int *H,
                                const int *W, const int *table_index, int B, int dtype, const void *tables_dev,
                                int K, int acc_mode, void *stream) {
@@ -328,8 +525,13 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   }
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
+  static int g_num_cus = 256;
   if (!attr_set) {
     DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    int dev = 0, cus = 0;
+    DIB_HIP_CHECK(hipGetDevice(&dev));
+    DIB_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus > 0) g_num_cus = cus;
     attr_set = true;
   }
   int i = 0;
@@ -342,9 +544,9 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       ImageDesc d;
       d.in = in_dev[i]; d.out = out_dev[i]; d.C = C[i]; d.H = H[i]; d.W = W[i]; d.table = table_index[i];
       d.tiles_x = (W[i] + TILE_W - 1) / TILE_W;
-      d.tiles_y32 = (H[i] + 31) / 32;
+      d.tiles_y = (H[i] + TH - 1) / TH;
       d.tile_begin = tiles;
-      tiles += d.C * d.tiles_x * d.tiles_y32;
+      tiles += d.C * d.tiles_x * d.tiles_y;
       tiled.img[tiled.n++] = d;
       long long n = (long long)C[i] * H[i] * W[i];
       d.tile_begin = gblocks;
@@ -355,9 +557,10 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     tiled.total_tiles = tiles;
     generic.total_tiles = gblocks;
     if (dtype == DIB_F16) {
-      hipLaunchKernelGGL(blur_tiled_f16_kernel, dim3(tiles), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K);
-      if (K == 256)  // column extents beyond 128 cannot be tiled; those images take the generic path
-        hipLaunchKernelGGL((blur_generic_kernel<__half, true>), dim3(gblocks), dim3(256), 0, s, generic, (const int *)tables_dev, K);
+      int nwg = g_num_cus * WG_PER_CU;
+      if (nwg > tiles) nwg = tiles;
+      hipLaunchKernelGGL(blur_tiled_f16_kernel, dim3(nwg), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K,
+                         g_stamp_buffer);
     } else {
       hipLaunchKernelGGL((blur_generic_kernel<float, false>), dim3(gblocks), dim3(256), 0, s, generic, (const int *)tables_dev, K);
     }
@@ -374,7 +577,7 @@ extern "C" int dib_sparse_blur_generic(const void *in_dev, void *out_dev, int C,
   BlurBatch g;
   g.n = 1;
   ImageDesc d;
-  d.in = in_dev; d.out = out_dev; d.C = C; d.H = H; d.W = W; d.table = 0; d.tile_begin = 0; d.tiles_x = d.tiles_y32 = 0;
+  d.in = in_dev; d.out = out_dev; d.C = C; d.H = H; d.W = W; d.table = 0; d.tile_begin = 0; d.tiles_x = d.tiles_y = 0;
   g.img[0] = d;
   int blocks = (int)(((long long)C * H * W + 255) / 256);
   g.total_tiles = blocks;

@@ -12,9 +12,21 @@ namespace dib {
 constexpr int HDR_NTAPS = 0, HDR_RMIN = 1, HDR_RMAX = 2, HDR_CMIN = 3, HDR_CMAX = 4, HDR_K = 5,
               HDR_SUM = 6, HDR_FLAGS = 7, HDR_WORDS = 8;
 
+// [7] = number of tap segments.  A segment is a run of consecutive (row-major) taps whose bounding
+// box spans at most SEG_ROWS+1 PSF rows and SEG_COLS+1 PSF columns: the unit the tiled blur stages
+// in LDS.  Entry = uint4 {first tap, end tap, (r_first << 8) | r_last, (cmin << 8) | cmax}.
+constexpr int HDR_NSEGS = 7;
+constexpr int SEG_ROWS = 16, SEG_COLS = 32;
+// LDS window geometry of the tiled blur (dib_blur.hip), needed here because the compaction kernel
+// pre-computes, per tap, the byte offset of its source word inside that window:
+//   ltap = ((r_last - r) * WIN_PITCH + (cmax - c)) * 8   |   fp16 weight bits << 16
+constexpr int WIN_PITCH = 64 + SEG_COLS;  // 8-byte words per LDS window row
+
 __host__ __device__ inline int table_rowptr_off() { return HDR_WORDS; }
-__host__ __device__ inline int table_taps_off(int K) { return (HDR_WORDS + K + 1 + 1) & ~1; }
-__host__ __device__ inline int table_words(int K) { return table_taps_off(K) + 2 * K * K; }
+__host__ __device__ inline int table_taps_off(int K) { return (HDR_WORDS + K + 1 + 3) & ~3; }
+__host__ __device__ inline int table_segs_off(int K) { return table_taps_off(K) + 2 * K * K; }
+__host__ __device__ inline int table_ltaps_off(int K) { return table_segs_off(K) + 4 * K * K; }
+__host__ __device__ inline int table_words(int K) { return table_ltaps_off(K) + K * K + 8; }
 
 // ---- padding modes of manual_blur (models/blur_functions.py:28-31, :55-58) ---------------
 enum PadMode { PAD_REFLECT = 0, PAD_ZERO = 1, PAD_REPLICATE = 2 };
@@ -62,7 +74,7 @@ struct ImageDesc {
   int table;       // index into the table array
   int tile_begin;  // first flattened tile id of this image in the launch
   int tiles_x;     // 256-px-wide tiles per row
-  int tiles_y32;   // 32-row tiles per channel (upper bound; 64-row classes use half of them)
+  int tiles_y;     // 32-row tiles per channel
 };
 
 struct BlurBatch {

@@ -1,14 +1,16 @@
-// Tap compaction for gfx950: one 256-thread workgroup per K x K PSF.
+// Tap compaction for gfx950: one 1024-thread workgroup per K x K PSF, single pass over the data.
 //
 // Replaces, for a whole batch and without any host synchronisation, the reference's
 //   psf_GPU = psf_GPU / psf_GPU.sum();  non_zero_points = psf_GPU.nonzero()
 // (models/blur_functions.py:98,63 and again utils.py:372-374) plus the min/max of the tap
-// coordinates that expand_targets needs (utils.py:376-380).
+// coordinates that expand_targets needs (utils.py:376-380), and cuts the tap list into the
+// bounded segments the tiled blur stages in LDS.
 //
 // fp16 semantics: the sum is formed EXACTLY (every finite fp16 is a multiple of 2^-24, so the
 // total is an int64 in those units) and rounded once to fp16 (round-to-nearest-even); the
 // division is an IEEE fp32 divide rounded to fp16, which equals a correctly rounded fp16 divide
-// (24 >= 2*11+2).  Order of the output taps = row-major, the order of torch.nonzero.
+// (24 >= 2*11+2).  Order of the output taps = row-major, the order of torch.nonzero: every thread
+// owns K*K/1024 CONSECUTIVE elements, so thread order is element order.
 #include "dib_common.h"
 #include <hip/hip_fp16.h>
 
@@ -68,48 +70,74 @@ template <typename A> __device__ inline A wave_sum(A v) {
   return v;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void psf_compact_kernel(const T *__restrict__ psf, int K, int normalize,
-                                                          int *__restrict__ tables) {
+constexpr int CT = 1024;          // threads per PSF
+constexpr int STAGE_TAPS = 4096;  // (row<<8|col) of the first taps are staged in LDS for the segmenter
+
+template <typename T, int K>
+__global__ __launch_bounds__(CT) void psf_compact_kernel(const T *__restrict__ psf, int normalize,
+                                                         int *__restrict__ tables) {
   using E = Elem<T>;
-  __shared__ typename E::Acc s_part[4];
-  __shared__ int s_cnt[1024 + 1];  // per 64-element chunk (K*K/64 <= 1024)
-  __shared__ int s_ext[4];         // rmin rmax cmin cmax
+  constexpr int N = K * K, EPT = N / CT, LK = (K == 128) ? 7 : 8, NWAVE = CT / 64;
+  __shared__ typename E::Acc s_part[NWAVE];
+  __shared__ int s_wtot[NWAVE];
+  __shared__ int s_ext[4];  // rmin rmax cmin cmax
   __shared__ T s_sum;
+  __shared__ unsigned short s_rc[STAGE_TAPS];
+  __shared__ unsigned short s_w16[STAGE_TAPS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = K * K, nchunks = n / 64, lk = (K == 128) ? 7 : 8;
-  const T *p = psf + (size_t)blockIdx.x * n;
+  const T *p = psf + (size_t)blockIdx.x * N + (size_t)tid * EPT;
   int *tab = tables + (size_t)blockIdx.x * table_words(K);
 
-  // ---- pass 1: sum -------------------------------------------------------------------
+  // ---- one vectorised read of this thread's EPT consecutive elements ---------------------------
+  T v[EPT];
+  {
+    constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte load
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+    for (int i = 0; i < EPT / VEC; ++i) {
+      uint4 q = p4[i];
+      const T *e = reinterpret_cast<const T *>(&q);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[i * VEC + k] = e[k];
+    }
+  }
+  if (tid < 4) s_ext[tid] = (tid & 1) ? -1 : K;
+
+  // ---- sum ------------------------------------------------------------------------------------
   T total = T(1.0f);
   if (normalize) {
     typename E::Acc acc = 0;
-    for (int i = tid; i < n; i += 256) acc += E::lift(p[i]);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) acc += E::lift(v[i]);
     acc = wave_sum(acc);
     if (lane == 0) s_part[wave] = acc;
     __syncthreads();
-    if (tid == 0) s_sum = E::finish(((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]);
+    if (tid == 0) {
+      typename E::Acc a = 0;
+      for (int k = 0; k < NWAVE; ++k) a += s_part[k];
+      s_sum = E::finish(a);
+    }
     __syncthreads();
     total = s_sum;
+  } else {
+    __syncthreads();
   }
-  if (tid < 4) s_ext[tid] = (tid & 1) ? -1 : K;
-  __syncthreads();
 
-  // ---- pass 2: per-chunk non-zero counts + extents -------------------------------------
+  // ---- weights, non-zero mask, extents ----------------------------------------------------------
+  unsigned long long mask = 0;
   int rmin = K, rmax = -1, cmin = K, cmax = -1;
-  for (int ch = wave; ch < nchunks; ch += 4) {
-    int i = ch * 64 + lane;
-    T w = normalize ? E::div(p[i], total) : p[i];
-    bool nz = E::nonzero(w);
-    unsigned long long m = __ballot(nz);
-    if (lane == 0) s_cnt[ch] = __popcll(m);
-    if (nz) {
-      int r = i >> lk, c = i & (K - 1);
+  const int e0 = tid * EPT;
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    if (normalize) v[i] = E::div(v[i], total);
+    if (E::nonzero(v[i])) {
+      mask |= 1ull << i;
+      const int r = (e0 + i) >> LK, c = (e0 + i) & (K - 1);
       rmin = min(rmin, r); rmax = max(rmax, r); cmin = min(cmin, c); cmax = max(cmax, c);
     }
   }
+  const int cnt = __popcll(mask);
   for (int off = 32; off > 0; off >>= 1) {
     rmin = min(rmin, __shfl_down(rmin, off, 64)); rmax = max(rmax, __shfl_down(rmax, off, 64));
     cmin = min(cmin, __shfl_down(cmin, off, 64)); cmax = max(cmax, __shfl_down(cmax, off, 64));
@@ -118,50 +146,98 @@ __global__ __launch_bounds__(256) void psf_compact_kernel(const T *__restrict__ 
     atomicMin(&s_ext[0], rmin); atomicMax(&s_ext[1], rmax);
     atomicMin(&s_ext[2], cmin); atomicMax(&s_ext[3], cmax);
   }
+
+  // ---- exclusive scan of the per-thread counts ----------------------------------------------------
+  int incl = cnt;
+  for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+  if (lane == 63) s_wtot[wave] = incl;
   __syncthreads();
+  int wbase = 0, ntaps = 0;
+  for (int k = 0; k < NWAVE; ++k) { if (k < wave) wbase += s_wtot[k]; ntaps += s_wtot[k]; }
+  int pos = wbase + incl - cnt;
 
-  // ---- exclusive scan of the chunk counts (<= 1024 entries, 4 per thread) ---------------
-  {
-    int base = tid * 4, v[4], s = 0;
-    for (int k = 0; k < 4; ++k) { v[k] = (base + k < nchunks) ? s_cnt[base + k] : 0; s += v[k]; }
-    // inclusive scan of s across 256 threads: wave scan + cross-wave fix-up
-    int incl = s;
-    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
-    __shared__ int s_wtot[4];
-    if (lane == 63) s_wtot[wave] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int k = 0; k < wave; ++k) wbase += s_wtot[k];
-    int excl = wbase + incl - s;
-    __syncthreads();
-    for (int k = 0; k < 4; ++k) { if (base + k < nchunks) s_cnt[base + k] = excl; excl += v[k]; }
-    if (tid == 255) s_cnt[nchunks] = excl;   // total (thread 255 owns the last chunks)
-    __syncthreads();
-  }
-  const int ntaps = s_cnt[nchunks];
-
-  // ---- header + CSR row pointers ---------------------------------------------------------
+  // ---- header, CSR row pointers, taps -----------------------------------------------------------------
+  constexpr int TPR = K / EPT;  // threads per PSF row
+  if ((tid % TPR) == 0) tab[table_rowptr_off() + tid / TPR] = pos;
   if (tid == 0) {
+    tab[table_rowptr_off() + K] = ntaps;
     tab[HDR_NTAPS] = ntaps;
     tab[HDR_RMIN] = s_ext[0]; tab[HDR_RMAX] = s_ext[1]; tab[HDR_CMIN] = s_ext[2]; tab[HDR_CMAX] = s_ext[3];
-    tab[HDR_K] = K; tab[HDR_SUM] = (int)E::bits(total); tab[HDR_FLAGS] = 0;
+    tab[HDR_K] = K; tab[HDR_SUM] = (int)E::bits(total);
   }
-  const int cpr = K / 64;  // chunks per PSF row
-  for (int r = tid; r <= K; r += 256) tab[table_rowptr_off() + r] = s_cnt[min(r * cpr, nchunks)];
-
-  // ---- pass 3: ordered write ----------------------------------------------------------------
   uint2 *taps = reinterpret_cast<uint2 *>(tab + table_taps_off(K));
-  for (int ch = wave; ch < nchunks; ch += 4) {
-    int i = ch * 64 + lane;
-    T w = normalize ? E::div(p[i], total) : p[i];
-    bool nz = E::nonzero(w);
-    unsigned long long m = __ballot(nz);
-    if (nz) {
-      int pos = s_cnt[ch] + __popcll(m & ((1ull << lane) - 1));
-      int r = i >> lk, c = i & (K - 1);
-      taps[pos] = make_uint2((unsigned)(r << 8 | c), E::bits(w));
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    if (mask & (1ull << i)) {
+      const unsigned rc = (unsigned)(((e0 + i) >> LK) << 8 | ((e0 + i) & (K - 1)));
+      taps[pos] = make_uint2(rc, E::bits(v[i]));
+      if (pos < STAGE_TAPS) { s_rc[pos] = (unsigned short)rc; s_w16[pos] = (unsigned short)E::bits(v[i]); }
+      ++pos;
     }
   }
+  __threadfence_block();
+  __syncthreads();
+  if (wave != 0) return;
+
+  // ---- segmentation (wave 0): greedy runs with row span <= SEG_ROWS and column span <= SEG_COLS --------
+  uint4 *segs = reinterpret_cast<uint4 *>(tab + table_segs_off(K));
+  unsigned *ltaps = reinterpret_cast<unsigned *>(tab + table_ltaps_off(K));
+  // per-tap LDS offsets of a closed segment [s0, s1) with last row rl and last column cmx
+  auto emit_ltaps = [&](int s0, int s1, int rl, int cmx) {
+    for (int j = s0 + lane; j < s1; j += 64) {
+      unsigned rcj, wj;
+      if (j < STAGE_TAPS) { rcj = s_rc[j]; wj = s_w16[j]; }
+      else { const uint2 tp = taps[j]; rcj = tp.x & 0xffffu; wj = tp.y & 0xffffu; }
+      const int rj = rcj >> 8, cj = rcj & 255;
+      ltaps[j] = (unsigned)(((rl - rj) * WIN_PITCH + (cmx - cj)) * 8) | (wj << 16);
+    }
+  };
+  int nseg = 0, seg_start = 0, seg_r0 = 0, seg_rlast = 0, car_cmin = 1 << 20, car_cmax = -1;
+  for (int base = 0; base < ntaps; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < ntaps;
+    unsigned rc = 0;
+    if (valid) rc = (i < STAGE_TAPS) ? s_rc[i] : (taps[i].x & 0xffffu);
+    const int r = rc >> 8, c = rc & 255;
+    if (base == 0) seg_r0 = __shfl(r, 0, 64);
+    int lo = 0;
+    while (true) {
+      // inclusive prefix min / max of c over lanes [lo, lane], joined with the open segment's carry
+      int pm = (valid && lane >= lo) ? c : (1 << 20), px = (valid && lane >= lo) ? c : -1;
+      for (int off = 1; off < 64; off <<= 1) {
+        int a = __shfl_up(pm, off, 64), b = __shfl_up(px, off, 64);
+        if (lane >= off) { pm = min(pm, a); px = max(px, b); }
+      }
+      pm = min(pm, car_cmin); px = max(px, car_cmax);
+      const bool bad = valid && lane >= lo && ((r - seg_r0 > SEG_ROWS) || (px - pm > SEG_COLS));
+      const unsigned long long fail = __ballot(bad);
+      const unsigned long long vmask = __ballot(valid);
+      const int last_valid = 63 - __clzll((long long)vmask);  // vmask != 0 inside the loop
+      if (fail == 0) {
+        car_cmin = __shfl(pm, last_valid, 64); car_cmax = __shfl(px, last_valid, 64);
+        seg_rlast = __shfl(r, last_valid, 64);
+        break;
+      }
+      const int f = __ffsll((long long)fail) - 1;  // tap base+f opens a new segment
+      int cmn = car_cmin, cmx = car_cmax, rl = seg_rlast;
+      if (f > lo) { cmn = __shfl(pm, f - 1, 64); cmx = __shfl(px, f - 1, 64); rl = __shfl(r, f - 1, 64); }
+      if (lane == 0) segs[nseg] = make_uint4(seg_start, base + f, (seg_r0 << 8) | rl, (cmn << 8) | cmx);
+      emit_ltaps(seg_start, base + f, rl, cmx);
+      ++nseg;
+      seg_start = base + f;
+      seg_r0 = __shfl(r, f, 64);
+      seg_rlast = seg_r0;
+      car_cmin = 1 << 20; car_cmax = -1;
+      lo = f;
+    }
+  }
+  if (ntaps > 0) {
+    if (lane == 0) segs[nseg] = make_uint4(seg_start, ntaps, (seg_r0 << 8) | seg_rlast, (car_cmin << 8) | car_cmax);
+    emit_ltaps(seg_start, ntaps, seg_rlast, car_cmax);
+    ++nseg;
+  }
+  if (lane < 8) ltaps[ntaps + lane] = 0;  // the blur's scalar prefetch runs up to two taps past the end
+  if (lane == 0) tab[HDR_NSEGS] = nseg;
 }
 
 }  // namespace dib
@@ -175,13 +251,15 @@ extern "C" int dib_psf_compact(const void *psf_dev, int dtype, int B, int K, int
                                void *stream) {
   if (!psf_dev || !tables_dev || B < 0) { dib::set_error("dib_psf_compact: null pointer or negative batch"); return DIB_EINVAL; }
   if (K != 128 && K != 256) { dib::set_error("dib_psf_compact: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
+  if (dtype != DIB_F16 && dtype != DIB_F32) { dib::set_error("dib_psf_compact: unknown dtype %d", dtype); return DIB_EINVAL; }
+  if (((uintptr_t)psf_dev & 15) != 0) { dib::set_error("dib_psf_compact: PSF pointer must be 16-byte aligned"); return DIB_EINVAL; }
   if (B == 0) return DIB_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == DIB_F16)
-    hipLaunchKernelGGL(dib::psf_compact_kernel<__half>, dim3(B), dim3(256), 0, s, (const __half *)psf_dev, K, normalize, (int *)tables_dev);
-  else if (dtype == DIB_F32)
-    hipLaunchKernelGGL(dib::psf_compact_kernel<float>, dim3(B), dim3(256), 0, s, (const float *)psf_dev, K, normalize, (int *)tables_dev);
-  else { dib::set_error("dib_psf_compact: unknown dtype %d", dtype); return DIB_EINVAL; }
+  int *t = (int *)tables_dev;
+  if (dtype == DIB_F16 && K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 128>), dim3(B), dim3(dib::CT), 0, s, (const __half *)psf_dev, normalize, t);
+  else if (dtype == DIB_F16) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 256>), dim3(B), dim3(dib::CT), 0, s, (const __half *)psf_dev, normalize, t);
+  else if (K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<float, 128>), dim3(B), dim3(dib::CT), 0, s, (const float *)psf_dev, normalize, t);
+  else hipLaunchKernelGGL((dib::psf_compact_kernel<float, 256>), dim3(B), dim3(dib::CT), 0, s, (const float *)psf_dev, normalize, t);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }

@@ -51,7 +51,11 @@ const char *dib_last_error(void);
  * two `psf/psf.sum()` + `psf.nonzero()` passes of the reference
  * (models/blur_functions.py:63,98 and utils.py:372-374) and their host synchronisations.
  * Layout (int32 words): [0]=ntaps [1]=rmin [2]=rmax [3]=cmin [4]=cmax [5]=K [6]=sum bits
- * [7]=flags | rowptr[K+1] | pad to even | taps[K*K] as {uint32 (row<<8|col), uint32 weight bits}.
+ * [7]=nsegs | rowptr[K+1] | pad to x4 | taps[K*K] as {uint32 (row<<8|col), uint32 weight bits}
+ * | segments[K*K] as {first tap, end tap, r_first<<8|r_last, cmin<<8|cmax} (runs of consecutive
+ * taps with a bounding box of at most 17 rows x 33 columns: the unit staged in LDS by the blur)
+ * | ltaps[K*K+8] one word per tap: byte offset of its source word in the blur's LDS window (low
+ * 16 bits) and the fp16 weight bits (high 16 bits).
  * ------------------------------------------------------------------------------------- */
 size_t dib_tap_table_bytes(int K); /* bytes of ONE table; K is 128 or 256 */
 

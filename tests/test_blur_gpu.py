@@ -191,3 +191,32 @@ def test_full_size_batch_vs_c_oracle_digest():
     for i in range(8):
         single = BF.manual_blur(imgs[i], _dev(O.normalize_psf(GI.golden_psf(0.005, i % 3, "half"))))
         assert torch.equal(batch[i], single)
+
+
+def test_segments_cover_taps_in_order_and_are_bounded():
+    """The tap list is cut into consecutive segments of at most 17 rows x 33 columns."""
+    from detectinblur_amd import blur_ops
+    rs = np.random.RandomState(77)
+    psfs = []
+    for sp, n in ((3, 20), (20, 150), (60, 600), (63, 3000)):
+        a = np.zeros((128, 128), np.float16)
+        rr = np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127)
+        cc = np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127)
+        a[rr, cc] = (rs.random_sample(n) + 0.1).astype(np.float16)
+        psfs.append(a)
+    a = np.zeros((128, 128), np.float16); a[64, :] = 0.01; psfs.append(a)      # one full-width row
+    a = np.zeros((128, 128), np.float16); a[:, 5] = 0.01; psfs.append(a)       # one full-height column
+    psfs.append(np.full((128, 128), 0.001, np.float16))                        # dense
+    tabs = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=False)
+    for k, a in enumerate(psfs):
+        rr, cc = np.nonzero(a)
+        segs = tabs.segments(k)
+        assert segs[0][0] == 0 and segs[-1][1] == len(rr)
+        for (s0, s1, rf, rl, cmn, cmx), nxt in zip(segs, segs[1:] + [None]):
+            assert s1 > s0
+            assert (rf, rl) == (rr[s0], rr[s1 - 1]) and rl - rf <= 16
+            assert (cmn, cmx) == (cc[s0:s1].min(), cc[s0:s1].max()) and cmx - cmn <= 32
+            if nxt is not None:
+                assert nxt[0] == s1
+                # greedy: the next tap could not have joined this segment
+                assert rr[s1] - rf > 16 or max(cmx, cc[s1]) - min(cmn, cc[s1]) > 32
