@@ -28,10 +28,12 @@ _SIGNATURES = {
     "dib_abi_version": (ctypes.c_int, []),
     "dib_last_error": (ctypes.c_char_p, []),
     "dib_tap_table_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "dib_tap_tables_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "dib_psf_compact": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p]),
     "dib_sparse_blur": (ctypes.c_int, [_c_void_pp, _c_void_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int,
-                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p]),
     "dib_expand_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p]),
     "dib_clamp_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

@@ -31,7 +31,8 @@ class TapTables:
         self.words = table_words(K)
         if self.words == 0:
             raise ValueError("PSF must be 128 or 256 wide, got %d" % K)
-        self.buf = torch.empty(count * self.words, dtype=torch.int32, device=device)
+        # `count` tables + the scheduler trailer (zeroed by dib_psf_compact)
+        self.buf = torch.empty(_lib.lib().dib_tap_tables_bytes(K, count) // 4, dtype=torch.int32, device=device)
 
     def ptr(self, i=0):
         return self.buf.data_ptr() + 4 * self.words * i
@@ -112,7 +113,8 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
         return outs
     _lib.check(_lib.lib().dib_sparse_blur(_lib.ptr_array(ins_p), _lib.ptr_array(outs_p), _lib.int_array(Cs),
                                           _lib.int_array(Hs), _lib.int_array(Ws), _lib.int_array(list(table_index)),
-                                          n, _DT[dt], tables.buf.data_ptr(), tables.K, acc_mode, _stream()))
+                                          n, _DT[dt], tables.buf.data_ptr(), tables.count, tables.K, acc_mode,
+                                          _stream()))
     return outs
 
 

@@ -28,6 +28,8 @@ __host__ __device__ inline int table_segs_off(int K) { return table_taps_off(K) 
 __host__ __device__ inline int table_ltaps_off(int K) { return table_segs_off(K) + 4 * K * K; }
 __host__ __device__ inline int table_words(int K) { return table_ltaps_off(K) + K * K + 8; }
 
+constexpr int SCHED_WORDS = 256;  // trailer behind the last table: 16 tile-queue words per blur launch
+
 // ---- padding modes of manual_blur (models/blur_functions.py:28-31, :55-58) ---------------
 enum PadMode { PAD_REFLECT = 0, PAD_ZERO = 1, PAD_REPLICATE = 2 };
 
@@ -79,6 +81,7 @@ struct ImageDesc {
 
 struct BlurBatch {
   ImageDesc img[MAX_BATCH];
+  int tile_begin[MAX_BATCH + 1];  // copy of img[i].tile_begin (+ total), contiguous for the image lookup
   int n;
   int total_tiles;
 };

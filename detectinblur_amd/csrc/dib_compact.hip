@@ -89,6 +89,9 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(const T *__restrict__ p
   const T *p = psf + (size_t)blockIdx.x * N + (size_t)tid * EPT;
   int *tab = tables + (size_t)blockIdx.x * table_words(K);
 
+  // scheduler trailer behind the last table: the blur's tile-queue tickets start from zero
+  if (blockIdx.x == 0 && tid < SCHED_WORDS) tables[(size_t)gridDim.x * table_words(K) + tid] = 0;
+
   // ---- one vectorised read of this thread's EPT consecutive elements ---------------------------
   T v[EPT];
   {
@@ -245,6 +248,11 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(const T *__restrict__ p
 extern "C" size_t dib_tap_table_bytes(int K) {
   if (K != 128 && K != 256) return 0;
   return (size_t)dib::table_words(K) * sizeof(int);
+}
+
+extern "C" size_t dib_tap_tables_bytes(int K, int B) {
+  if ((K != 128 && K != 256) || B < 0) return 0;
+  return ((size_t)dib::table_words(K) * B + dib::SCHED_WORDS) * sizeof(int);
 }
 
 extern "C" int dib_psf_compact(const void *psf_dev, int dtype, int B, int K, int normalize, void *tables_dev,

@@ -1,14 +1,14 @@
-import sys, os
+import sys, os, ctypes
 sys.path.insert(0, '.')
 import numpy as np, torch
 import bench
-from detectinblur_amd import blur_ops
+from detectinblur_amd import blur_ops, _lib
 images, dicts, psfs, psfs_host, _ = bench.make_workload(0, torch.device("cuda", 0))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+nw = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 tables = blur_ops.compact_psfs(psfs, normalize=True)
 idx = list(range(8))
 for _ in range(n):
     tables = blur_ops.compact_psfs(psfs, normalize=True)
     blur_ops.sparse_blur(list(images), idx, tables)
 torch.cuda.synchronize()
-print("segments per psf:", [len(tables.segments(i)) for i in range(8)], "taps", [tables.header(i)[0] for i in range(8)], "ext", [tables.header(i)[1:] for i in range(8)])

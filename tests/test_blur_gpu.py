@@ -220,3 +220,25 @@ def test_segments_cover_taps_in_order_and_are_bounded():
                 assert nxt[0] == s1
                 # greedy: the next tap could not have joined this segment
                 assert rr[s1] - rf > 16 or max(cmx, cc[s1]) - min(cmn, cc[s1]) > 32
+
+
+def test_repeated_full_size_batches_are_deterministic(golden):
+    """The persistent tile queue and the hand-written tap loop under load: 6 back-to-back batches of
+    8 x 3x800x1333 through ONE set of tap tables must all be bit-identical and match the golden
+    digest where the inputs coincide (image seed 1337 + PSF p0.005/E1 = blur_full_e1_f16)."""
+    from detectinblur_amd import blur_ops
+    case = [c for c in GI.blur_cases() if c["name"] == "full_e1_f16"][0]
+    imgs = [_dev(GI.make_image(case))] + [torch.rand(3, 800, 1333, generator=torch.Generator().manual_seed(50 + i)).half().cuda()
+                                          for i in range(7)]
+    psfs = [_dev(GI.golden_psf(0.005, 1, "half"))] + [_dev(GI.golden_psf(0.005, i % 5, "half")) for i in range(7)]
+    tables = blur_ops.compact_psfs(psfs, normalize=True)
+    first = None
+    for rep in range(6):
+        outs = blur_ops.sparse_blur(list(imgs), list(range(8)), tables)
+        if first is None:
+            first = [o.clone() for o in outs]
+            got = outs[0].cpu().numpy()
+            assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == golden.meta["blur_full_e1_f16"]["sha256"]
+        else:
+            for a, b in zip(first, outs):
+                assert torch.equal(a, b)
