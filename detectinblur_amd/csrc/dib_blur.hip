@@ -40,7 +40,7 @@ constexpr int TILE_W = 256;
 constexpr int PQ = WIN_PITCH;         // LDS row pitch in 8-byte words (96)
 constexpr int TH = 32;                // tile rows
 constexpr int LROWS = TH + SEG_ROWS;  // LDS rows per window (48)
-constexpr int LDS_BYTES = LROWS * PQ * 8 + 16;  // window + ticket slot: 36,880 B, four workgroups per CU
+constexpr int LDS_BYTES = LROWS * PQ * 8;  // 36,864 B: four workgroups per CU
 static_assert(WIN_PITCH * 8 == 768, "the asm below hard-codes the LDS row pitch");
 
 // 64-bit asm operands must be scalar integers: hipcc (ROCm 7.2) aliases both lanes of a
@@ -53,15 +53,88 @@ typedef unsigned long long u2;
 // it from several asm statements costs ~20 scalar instructions per tap in glue (asm results count
 // as divergent, so loop-carried scalars bounce through VGPRs).  The whole loop of one tap segment
 // is therefore ONE asm statement with fixed buffer registers:
-//     v[40:47]  buffer A: the 4 rows x 8 bytes of the current tap, multiplied in place
-//     v[48:55]  buffer B: same for the following tap (the two alternate)
-//     v56       LDS address
+//     v[64:79]  buffer A: the 8 rows x 8 bytes of the current tap, multiplied in place
+//     v[80:95]  buffer B: same for the following tap (the two alternate)
+//     v96       LDS address
 //   per tap:  s_waitcnt lgkmcnt(0)          data of this tap + ltap word of the next one arrived
-//             4 x ds_read_b64 -> other buf  next tap's data (address = its ltap offset + lane base)
+//             8 x ds_read_b64 -> other buf  next tap's data (address = its ltap offset + lane base)
 //             s_load_dword                  ltap word of the tap after next
-//             8 x v_pk_mul_f16, 8 x v_pk_add_f16 on this tap's data while all of that is in flight
-// ~10 scalar + 1 vector instruction of overhead per tap instead of ~25.
+//             16 x v_pk_mul_f16, 16 x v_pk_add_f16 on this tap's data while all of that is in flight
+// ~10 scalar + 1 vector instruction of overhead per 32 packed operations.
 // ltap word = byte offset of the tap's source word in the window (low 16) | fp16 weight (high 16).
+// Operands: %0-%15 accumulators, %16 byte offset of the next ltap, %17 taps left, %18 A (tap being
+// multiplied), %19 B (tap being fetched), %20 C (tap in flight), %21 scalar temp, %22 ltaps, %23 lane base.
+#define DIB_MUL(b, i) "v_pk_mul_f16 v" #b ", %21, v" #b "\n\t"
+#define DIB_ADD(b, i) "v_pk_add_f16 %" #i ", %" #i ", v" #b "\n\t"
+#define DIB_MADD_A                                                                                          \
+  "s_lshr_b32 %21, %18, 16\n\ts_pack_ll_b32_b16 %21, %21, %21\n\t"                                            \
+  DIB_MUL(64, 0) DIB_MUL(65, 1) DIB_MUL(66, 2) DIB_MUL(67, 3) DIB_MUL(68, 4) DIB_MUL(69, 5) DIB_MUL(70, 6) DIB_MUL(71, 7) \
+  DIB_MUL(72, 8) DIB_MUL(73, 9) DIB_MUL(74, 10) DIB_MUL(75, 11) DIB_MUL(76, 12) DIB_MUL(77, 13) DIB_MUL(78, 14) DIB_MUL(79, 15) \
+  DIB_ADD(64, 0) DIB_ADD(65, 1) DIB_ADD(66, 2) DIB_ADD(67, 3) DIB_ADD(68, 4) DIB_ADD(69, 5) DIB_ADD(70, 6) DIB_ADD(71, 7) \
+  DIB_ADD(72, 8) DIB_ADD(73, 9) DIB_ADD(74, 10) DIB_ADD(75, 11) DIB_ADD(76, 12) DIB_ADD(77, 13) DIB_ADD(78, 14) DIB_ADD(79, 15)
+#define DIB_MADD_B                                                                                          \
+  "s_lshr_b32 %21, %18, 16\n\ts_pack_ll_b32_b16 %21, %21, %21\n\t"                                            \
+  DIB_MUL(80, 0) DIB_MUL(81, 1) DIB_MUL(82, 2) DIB_MUL(83, 3) DIB_MUL(84, 4) DIB_MUL(85, 5) DIB_MUL(86, 6) DIB_MUL(87, 7) \
+  DIB_MUL(88, 8) DIB_MUL(89, 9) DIB_MUL(90, 10) DIB_MUL(91, 11) DIB_MUL(92, 12) DIB_MUL(93, 13) DIB_MUL(94, 14) DIB_MUL(95, 15) \
+  DIB_ADD(80, 0) DIB_ADD(81, 1) DIB_ADD(82, 2) DIB_ADD(83, 3) DIB_ADD(84, 4) DIB_ADD(85, 5) DIB_ADD(86, 6) DIB_ADD(87, 7) \
+  DIB_ADD(88, 8) DIB_ADD(89, 9) DIB_ADD(90, 10) DIB_ADD(91, 11) DIB_ADD(92, 12) DIB_ADD(93, 13) DIB_ADD(94, 14) DIB_ADD(95, 15)
+#define DIB_READ8(base)                                                                                      \
+  "s_and_b32 %21, %19, 0xffff\n\tv_add_u32 v96, %21, %23\n\t"                                                 \
+  "ds_read_b64 v[" #base ":" #base "+1], v96\n\tds_read_b64 v[" #base "+2:" #base "+3], v96 offset:768\n\t"   \
+  "ds_read_b64 v[" #base "+4:" #base "+5], v96 offset:1536\n\tds_read_b64 v[" #base "+6:" #base "+7], v96 offset:2304\n\t" \
+  "ds_read_b64 v[" #base "+8:" #base "+9], v96 offset:3072\n\tds_read_b64 v[" #base "+10:" #base "+11], v96 offset:3840\n\t" \
+  "ds_read_b64 v[" #base "+12:" #base "+13], v96 offset:4608\n\tds_read_b64 v[" #base "+14:" #base "+15], v96 offset:5376\n\t"
+#define DIB_NEXTTAP "s_load_dword %20, %22, %16\n\ts_add_u32 %16, %16, 4\n\t"
+
+// acc[i][0] / acc[i][1] (i = 0..7): the packed fp16 accumulators of this lane's 8 rows x 4 columns
+__device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n);
+  unsigned sA, sB, sC, st;
+  unsigned a[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[2 * i] = __builtin_bit_cast(unsigned, acc[i][0]); a[2 * i + 1] = __builtin_bit_cast(unsigned, acc[i][1]); }
+  asm volatile(
+      // vmcnt(0): window loads whose values were never used (rows past the window's end) may still be
+      // in flight, and hipcc is free to have put their destinations into the registers clobbered
+      // here -- it waits before ITS OWN next write to such a register, but not before this asm's.
+      // prologue: ltap[t0] -> B, ltap[t0+1] -> C, data of tap t0 -> buffer A
+      "s_load_dword %19, %22, %16\n\ts_add_u32 %16, %16, 4\n\t" DIB_NEXTTAP
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIB_READ8(64)
+      "Ldib_loop%=:\n\t"
+      // ---- tap in buffer A ----
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t"
+      "s_cmp_eq_u32 %17, 1\n\ts_cbranch_scc1 Ldib_lastA%=\n\t"
+      DIB_READ8(80) DIB_NEXTTAP
+      "Ldib_lastA%=:\n\t"
+      DIB_MADD_A
+      "s_sub_u32 %17, %17, 1\n\ts_cmp_eq_u32 %17, 0\n\ts_cbranch_scc1 Ldib_done%=\n\t"
+      // ---- tap in buffer B ----
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t"
+      "s_cmp_eq_u32 %17, 1\n\ts_cbranch_scc1 Ldib_lastB%=\n\t"
+      DIB_READ8(64) DIB_NEXTTAP
+      "Ldib_lastB%=:\n\t"
+      DIB_MADD_B
+      "s_sub_u32 %17, %17, 1\n\ts_cmp_eq_u32 %17, 0\n\ts_cbranch_scc0 Ldib_loop%=\n\t"
+      "Ldib_done%=:\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]),
+        "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+s"(toff), "+s"(cnt), "=&s"(sA), "=&s"(sB),
+        "=&s"(sC), "=&s"(st)
+      : "s"(ltaps), "v"(lane_addr)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80",
+        "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "scc",
+        "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { acc[i][0] = __builtin_bit_cast(h2, a[2 * i]); acc[i][1] = __builtin_bit_cast(h2, a[2 * i + 1]); }
+}
+#undef DIB_MUL
+#undef DIB_ADD
+#undef DIB_MADD_A
+#undef DIB_MADD_B
+#undef DIB_READ8
+#undef DIB_NEXTTAP
+
+// ---- the same loop for 8 waves x 4 rows per lane (buffers v[40:47] / v[48:55], address v56) ----------
 #define DIB_MADD(b0, b1, b2, b3, b4, b5, b6, b7)                                                        \
   "s_lshr_b32 %13, %10, 16\n\ts_pack_ll_b32_b16 %13, %13, %13\n\t"                                        \
   "v_pk_mul_f16 " b0 ", %13, " b0 "\n\tv_pk_mul_f16 " b1 ", %13, " b1 "\n\tv_pk_mul_f16 " b2 ", %13, " b2 "\n\t" \
@@ -231,8 +304,8 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
     if (sg == 0) stamp(dbg, 1);
 
     // ---- accumulate: taps of the segment in row-major order (hand-written loop above) -----------------
-    static_assert(R == 4, "tap_loop_r4 is written for 8 waves x 4 rows");
-    tap_loop_r4(acc, ltaps, t0, n, lane_addr);
+    if constexpr (R == 8) tap_loop_r8(acc, ltaps, t0, n, lane_addr);
+    else tap_loop_r4(acc, ltaps, t0, n, lane_addr);
     if (sg == 0) stamp(dbg, 2);
   }
 
@@ -267,69 +340,38 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
   }
 }
 
-// Persistent launch: 4 workgroups of 8 waves per CU (the 32-wave limit), each pulling
-// (image, channel, 256 x 32 tile) items of the flattened [image][channel][ty][tx] list from a
-// device-side queue.  Relaunching a workgroup per tile left a quarter of the wave slots empty
-// (measured: ~2.7 of 4 workgroups resident per CU, dispatch + prologue between tiles); a queue also
-// balances PSFs of different tap counts by itself.
-// The queue is sharded per XCD: one ticket word saturates at ~88 returning atomics per microsecond
-// (MI355X_MICROARCH.md, row `dequeue`) and this kernel retires ~70 tiles per microsecond, so with a
-// single word the dequeue itself became the bottleneck.  Shard x hands out tiles x, x+8, x+16, ...
-// to the workgroups running on XCD x (HW_REG_XCC_ID); interleaving gives every XCD the same mix of
-// images.  The ticket of the NEXT tile is requested before the current tile is processed.
-// q[0..7] = per-XCD tickets, q[8] = workgroups retired; all start at zero (dib_psf_compact clears
-// the trailer they live in) and are returned to zero by the last workgroup out.
-template <int NW>
+// Grid: one 256-thread workgroup per (image, channel, 256 x 32 tile) in the flattened order
+// [image][channel][ty][tx]; four workgroups fit a CU (36 KB of LDS each).  Consecutive tiles land on
+// different XCDs (round-robin dispatch), which spreads every image -- and its tap count -- evenly
+// over the chip; the hardware dispatcher refills a CU as soon as a workgroup retires.
+// (Measured alternatives, scratch/: a persistent kernel pulling tiles from an XCD-sharded atomic
+// queue was 30-60 % slower -- the returning atomics and the per-tile descriptor fetches sit on the
+// critical path of every tile, and static striding loses ~20 us to tap-count imbalance; 8-wave
+// workgroups double the wave launches, whose rate bounds this kernel at ~32 us for 28,800 waves.)
+template <int NW, int TPW>
 __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K,
-                                                                     int *__restrict__ q, unsigned long long *dbg) {
+                                                                     unsigned long long *dbg) {
   extern __shared__ uint2 lds[];
-  // the ticket slot sits BEHIND the window so that the window keeps its 16-byte-aligned base
-  int &s_next = *reinterpret_cast<int *>(lds + LROWS * PQ);
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const int shard = (int)(xcc & 7u);
-  if (threadIdx.x == 0) s_next = atomicAdd(q + shard, 1);
-  __syncthreads();
-  int tile = __builtin_amdgcn_readfirstlane(s_next) * 8 + shard;
-  unsigned long long w_start = 0, c_dec = 0, c_tile = 0, c_bar = 0, tq = 0;
-  int ntiles = 0;
-  if (dbg) { w_start = wall_clock64(); tq = __builtin_readcyclecounter(); }
-#define DIB_TICK(var) do { if (dbg) { unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - tq; tq = now_; } } while (0)
-  while (tile < batch.total_tiles) {
-    int next_ticket = 0;
-    if (threadIdx.x == 0) next_ticket = atomicAdd(q + shard, 1);
-    // image lookup: tile_begin[] is contiguous in the kernel arguments (a handful of scalar loads)
-    int i = 0;
+  const int tile = blockIdx.x;
+  // image lookup: tile_begin[] is contiguous in the kernel arguments (a handful of scalar loads)
+  int i = 0;
 #pragma unroll
-    for (int k = 1; k < MAX_BATCH; ++k)
-      if (k < batch.n && tile >= batch.tile_begin[k]) i = k;
-    const ImageDesc &d = batch.img[i];
-    int local = tile - d.tile_begin;
-    const int per_ch = d.tiles_x * d.tiles_y;
-    const int ch = local / per_ch;
-    local -= ch * per_ch;
-    const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
-    const int *tab = tables + (size_t)d.table * table_words(K);
-    DIB_TICK(c_dec);
-    if (pad_mode_for(K, d.H, d.W) == PAD_ZERO) blur_tile_f16<NW, true>(d, tab, K, ch, tx, ty, lds, dbg);
+  for (int k = 1; k < MAX_BATCH; ++k)
+    if (k < batch.n && tile >= batch.tile_begin[k]) i = k;
+  const ImageDesc &d = batch.img[i];
+  int local = tile - d.tile_begin;
+  const int per_ch = d.tiles_x * d.tiles_y;   // tiles_y counts STACKS of TPW vertically adjacent tiles
+  const int ch = local / per_ch;
+  local -= ch * per_ch;
+  const int sy = local / d.tiles_x, tx = local - sy * d.tiles_x;
+  const int *tab = tables + (size_t)d.table * table_words(K);
+  const bool zero = pad_mode_for(K, d.H, d.W) == PAD_ZERO;
+  for (int rep = 0; rep < TPW; ++rep) {
+    const int ty = sy * TPW + rep;
+    if (ty * TH >= d.H) break;
+    if (rep > 0) __syncthreads();  // the previous tile's window reads are over
+    if (zero) blur_tile_f16<NW, true>(d, tab, K, ch, tx, ty, lds, dbg);
     else blur_tile_f16<NW, false>(d, tab, K, ch, tx, ty, lds, dbg);
-    DIB_TICK(c_tile);
-    if (threadIdx.x == 0) s_next = next_ticket;
-    __syncthreads();  // also fences this tile's LDS window reads from the next tile's fill
-    tile = __builtin_amdgcn_readfirstlane(s_next) * 8 + shard;  // keep the loop state provably wave-uniform
-    DIB_TICK(c_bar);
-    ++ntiles;
-  }
-  if (dbg && threadIdx.x == 0) {
-    unsigned long long *o = dbg + (size_t)gridDim.x * 8 + (size_t)blockIdx.x * 8;
-    o[0] = w_start; o[1] = wall_clock64(); o[2] = c_dec; o[3] = c_tile; o[4] = c_bar; o[5] = (unsigned long long)ntiles;
-  }
-  // Leave the queue as it was found: the last workgroup out (every other one has taken its final
-  // ticket by then) zeroes all words, so the same tables serve any number of blur calls.
-  if (threadIdx.x == 0) {
-    if (atomicAdd(q + 8, 1) == (int)gridDim.x - 1) {
-      for (int k = 0; k < 9; ++k) atomicExch(q + k, 0);
-    }
   }
 }
 
@@ -385,6 +427,9 @@ using namespace dib;
 // Diagnostics only: when set, the tiled kernel records per-workgroup phase stamps (8 x u64 each).
 static unsigned long long *g_stamp_buffer = nullptr;
 extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) { g_stamp_buffer = (unsigned long long *)dev_ptr; }
+// Tuning knobs (all variants are bit-identical): waves per workgroup (4 or 8), tiles per workgroup (1 or 2)
+static int g_nw = 4, g_tpw = 1;
+extern "C" void dib_debug_set_variant(int nw, int tpw) { g_nw = (nw == 4) ? 4 : 8; g_tpw = (tpw == 2) ? 2 : 1; }
 
 
 extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, const int *C, const int *H,
@@ -415,17 +460,13 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     if (table_index[i] >= num_tables) { set_error("dib_sparse_blur: table_index[%d] = %d out of range", i, table_index[i]); return DIB_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
-  static int num_cus = 256;
   if (!attr_set) {
-    DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    int dev = 0, cus = 0;
-    DIB_HIP_CHECK(hipGetDevice(&dev));
-    DIB_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus > 0) num_cus = cus;
+    DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
-  int *sched = (int *)tables_dev + (size_t)num_tables * table_words(K);
-  int launch = 0;
   int i = 0;
   while (i < B) {
     BlurBatch tiled, generic;
@@ -436,7 +477,7 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       ImageDesc d;
       d.in = in_dev[i]; d.out = out_dev[i]; d.C = C[i]; d.H = H[i]; d.W = W[i]; d.table = table_index[i];
       d.tiles_x = (W[i] + TILE_W - 1) / TILE_W;
-      d.tiles_y = (H[i] + TH - 1) / TH;
+      d.tiles_y = (H[i] + TH * g_tpw - 1) / (TH * g_tpw);
       d.tile_begin = tiles;
       tiled.tile_begin[tiled.n] = tiles;
       tiles += d.C * d.tiles_x * d.tiles_y;
@@ -450,13 +491,11 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     tiled.total_tiles = tiles;
     generic.total_tiles = gblocks;
     if (dtype == DIB_F16) {
-      if (16 * (launch + 1) > SCHED_WORDS) { set_error("dib_sparse_blur: more than %d launches in one call", SCHED_WORDS); return DIB_EINVAL; }
       for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
-      int nwg = num_cus * 4;  // 4 workgroups x 8 waves = the CU's 32 wave slots
-      if (nwg > tiles) nwg = tiles;
-      hipLaunchKernelGGL(blur_tiled_f16_kernel<8>, dim3(nwg), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, sched + 16 * launch,
-                         g_stamp_buffer);
-      ++launch;
+      if (g_nw == 4 && g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1>), dim3(tiles), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else if (g_nw == 4) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 2>), dim3(tiles), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else if (g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 1>), dim3(tiles), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 2>), dim3(tiles), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
     } else {
       hipLaunchKernelGGL((blur_generic_kernel<float, false>), dim3(gblocks), dim3(256), 0, s, generic, (const int *)tables_dev, K);
     }

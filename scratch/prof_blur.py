@@ -5,7 +5,7 @@ import bench
 from detectinblur_amd import blur_ops, _lib
 images, dicts, psfs, psfs_host, _ = bench.make_workload(0, torch.device("cuda", 0))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-nw = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 tables = blur_ops.compact_psfs(psfs, normalize=True)
 idx = list(range(8))
 for _ in range(n):

@@ -7,6 +7,7 @@ images, dicts, psfs, psfs_host, _ = bench.make_workload(0, torch.device("cuda", 
 tables = blur_ops.compact_psfs(psfs, normalize=True)
 idx = list(range(8))
 l = _lib.lib(); l.dib_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]; l.dib_debug_set_stamp_buffer.restype = None
+l.dib_debug_set_sched.argtypes=[ctypes.c_int]; l.dib_debug_set_sched.restype=None; l.dib_debug_set_sched(int(sys.argv[1]) if len(sys.argv)>1 else 0)
 for _ in range(5): blur_ops.sparse_blur(list(images), idx, tables)
 torch.cuda.synchronize()
 nblk = 1024

@@ -242,3 +242,32 @@ def test_repeated_full_size_batches_are_deterministic(golden):
         else:
             for a, b in zip(first, outs):
                 assert torch.equal(a, b)
+
+
+def test_kernel_variants_are_bit_identical():
+    """The 4-wave / 8-wave workgroup variants (two hand-written tap loops) and the 1- / 2-tile-per-
+    workgroup variants must agree bit for bit with the oracle on a ragged batch of all PSF classes."""
+    import ctypes
+    from detectinblur_amd import _lib, blur_ops
+    l = _lib.lib()
+    l.dib_debug_set_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+    l.dib_debug_set_variant.restype = None
+    rs = np.random.RandomState(11)
+    imgs, psfs = [], []
+    for sh, sp in zip([(3, 97, 301), (1, 65, 65), (2, 130, 257), (3, 70, 513), (3, 33, 140)], [2, 14, 30, 63, 8]):
+        imgs.append(rs.random_sample(sh).astype(np.float16))
+        a = np.zeros((128, 128), np.float64)
+        n = 8 + 4 * sp
+        a[np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127), np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127)] = rs.random_sample(n) + 0.01
+        psfs.append(O.to_half_like_torch(a * 0.2))
+    want = [a.copy() for a in imgs]
+    O.blur_image_list(want, [{"blurring": True}] * len(imgs), psfs)
+    tables = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=True)
+    try:
+        for nw, tpw in ((8, 1), (8, 2), (4, 2), (4, 1)):
+            l.dib_debug_set_variant(nw, tpw)
+            outs = blur_ops.sparse_blur([_dev(a) for a in imgs], list(range(len(imgs))), tables)
+            for g, w in zip(outs, want):
+                assert np.array_equal(_bits(g.cpu().numpy().squeeze()), _bits(w)), (nw, tpw)
+    finally:
+        l.dib_debug_set_variant(4, 1)
