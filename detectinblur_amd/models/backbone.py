@@ -1,0 +1,132 @@
+"""ResNet-50 + FPN trunk of `fasterrcnn_resnet50_fpn` (reference models/faster_rcnn.py:367 builds it
+with torchvision's `resnet_fpn_backbone('resnet50', ...)`).  Stock PyTorch modules only: the
+convolutions run on MIOpen / hipBLASLt (MFMA); nothing here is hand-written.
+
+Layout matches torchvision's so that published checkpoints load unchanged:
+`body.conv1 / body.bn1 / body.layer{1..4}.{i}.{conv,bn}{1,2,3} / downsample.{0,1}` and
+`fpn.inner_blocks.{0..3} / fpn.layer_blocks.{0..3}`; batch-norm layers are frozen affine maps.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm with fixed statistics and affine parameters: y = x * scale + shift."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, x):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        shift = self.bias - self.running_mean * scale
+        return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=FrozenBatchNorm2d):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)   # stride on the 3x3 (ResNet v1.5)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = norm_layer(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = F.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return F.relu(out + idt)
+
+
+class ResNet50Body(nn.Module):
+    def __init__(self, norm_layer=FrozenBatchNorm2d):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.inplanes = 64
+        self.layer1 = self._stage(64, 3, 1, norm_layer)
+        self.layer2 = self._stage(128, 4, 2, norm_layer)
+        self.layer3 = self._stage(256, 6, 2, norm_layer)
+        self.layer4 = self._stage(512, 3, 2, norm_layer)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _stage(self, planes, blocks, stride, norm_layer):
+        down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False), norm_layer(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, down, norm_layer)]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes, norm_layer=norm_layer) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        c2 = self.layer1(x)
+        c3 = self.layer2(c2)
+        c4 = self.layer3(c3)
+        c5 = self.layer4(c4)
+        return [c2, c3, c4, c5]
+
+
+class FeaturePyramidNetwork(nn.Module):
+    """Top-down pathway with lateral 1x1 and output 3x3 convolutions, plus a stride-2 max-pool level."""
+
+    def __init__(self, in_channels_list, out_channels):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList([nn.Conv2d(c, out_channels, 1) for c in in_channels_list])
+        self.layer_blocks = nn.ModuleList([nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels_list])
+        for m in self.children():
+            for conv in m:
+                nn.init.kaiming_uniform_(conv.weight, a=1)
+                nn.init.constant_(conv.bias, 0)
+
+    def forward(self, feats):
+        last = self.inner_blocks[-1](feats[-1])
+        outs = [self.layer_blocks[-1](last)]
+        for i in range(len(feats) - 2, -1, -1):
+            lateral = self.inner_blocks[i](feats[i])
+            last = lateral + F.interpolate(last, size=lateral.shape[-2:], mode="nearest")
+            outs.insert(0, self.layer_blocks[i](last))
+        outs.append(F.max_pool2d(outs[-1], 1, 2, 0))
+        return OrderedDict(zip(["0", "1", "2", "3", "pool"], outs))
+
+
+class BackboneWithFPN(nn.Module):
+    def __init__(self, trainable_layers=5, out_channels=256):
+        super().__init__()
+        self.body = ResNet50Body()
+        # freeze everything outside the last `trainable_layers` of (layer4, layer3, layer2, layer1, conv1)
+        keep = ["layer4", "layer3", "layer2", "layer1", "conv1"][:trainable_layers]
+        for name, p in self.body.named_parameters():
+            if not any(name.startswith(k) for k in keep):
+                p.requires_grad_(False)
+        self.fpn = FeaturePyramidNetwork([256, 512, 1024, 2048], out_channels)
+        self.out_channels = out_channels
+
+    def forward(self, x):
+        return self.fpn(self.body(x))
+
+
+def resnet_fpn_backbone(backbone_name="resnet50", pretrained=False, trainable_layers=3):
+    if backbone_name != "resnet50":
+        raise ValueError("only resnet50 is built here (SURVEY.md section 2: other trunks are out of scope)")
+    if pretrained:
+        raise RuntimeError("no network access: load ImageNet weights with model.backbone.body.load_state_dict(...)")
+    return BackboneWithFPN(trainable_layers)

@@ -1,0 +1,295 @@
+"""Box / RoI primitives of the detector (torchvision is not installed, so they live here).
+
+On CUDA tensors `roi_align` and `nms` run the hand-written HIP kernels of csrc/dib_roi.hip through
+the C ABI (and raise if libdib_hip.so is missing); on CPU tensors -- the gloo DDP tests and the
+fp32 reference used by the numerics tests -- they run the plain-PyTorch restatements below.
+Semantics: torchvision.ops.{roi_align(aligned=False), nms, batched_nms, box_iou, clip_boxes_to_image,
+remove_small_boxes}, which the reference's RPN / RoIHeads call (reference models/faster_rcnn.py:7-16).
+"""
+import math
+
+import torch
+
+from .. import _lib
+
+# ------------------------------------------------------------------------------------------------
+# boxes
+# ------------------------------------------------------------------------------------------------
+
+
+def box_area(b):
+    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+
+def box_iou(a, b):
+    """[N,4] x [M,4] -> [N,M]"""
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (box_area(a)[:, None] + box_area(b)[None, :] - inter)
+
+
+def clip_boxes_to_image(boxes, size):
+    h, w = size
+    x = boxes[..., 0::2].clamp(min=0, max=w)
+    y = boxes[..., 1::2].clamp(min=0, max=h)
+    return torch.stack((x[..., 0], y[..., 0], x[..., 1], y[..., 1]), dim=-1)
+
+
+def remove_small_boxes(boxes, min_size):
+    ws, hs = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    return torch.where((ws >= min_size) & (hs >= min_size))[0]
+
+
+class BoxCoder(object):
+    """R-CNN box parameterisation (dx, dy, dw, dh) with per-coordinate weights."""
+
+    def __init__(self, weights, clip=math.log(1000.0 / 16)):
+        self.weights = weights
+        self.clip = clip
+
+    def encode(self, reference, proposals):
+        wx, wy, ww, wh = self.weights
+        pw = proposals[:, 2] - proposals[:, 0]
+        ph = proposals[:, 3] - proposals[:, 1]
+        px = proposals[:, 0] + 0.5 * pw
+        py = proposals[:, 1] + 0.5 * ph
+        gw = reference[:, 2] - reference[:, 0]
+        gh = reference[:, 3] - reference[:, 1]
+        gx = reference[:, 0] + 0.5 * gw
+        gy = reference[:, 1] + 0.5 * gh
+        return torch.stack((wx * (gx - px) / pw, wy * (gy - py) / ph, ww * torch.log(gw / pw), wh * torch.log(gh / ph)), dim=1)
+
+    def decode(self, deltas, boxes):
+        """deltas [N, 4*k], boxes [N, 4] -> [N, k, 4]"""
+        boxes = boxes.to(deltas.dtype)
+        wx, wy, ww, wh = self.weights
+        w = boxes[:, 2] - boxes[:, 0]
+        h = boxes[:, 3] - boxes[:, 1]
+        cx = boxes[:, 0] + 0.5 * w
+        cy = boxes[:, 1] + 0.5 * h
+        dx = deltas[:, 0::4] / wx
+        dy = deltas[:, 1::4] / wy
+        dw = torch.clamp(deltas[:, 2::4] / ww, max=self.clip)
+        dh = torch.clamp(deltas[:, 3::4] / wh, max=self.clip)
+        pcx = dx * w[:, None] + cx[:, None]
+        pcy = dy * h[:, None] + cy[:, None]
+        pw = torch.exp(dw) * w[:, None]
+        ph = torch.exp(dh) * h[:, None]
+        return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=2)
+
+
+class Matcher(object):
+    """Assigns each prediction the ground truth of highest IoU, -1 below `low`, -2 between."""
+    BELOW_LOW = -1
+    BETWEEN = -2
+
+    def __init__(self, high, low, allow_low_quality_matches=False):
+        self.high, self.low, self.allow_low = high, low, allow_low_quality_matches
+
+    def __call__(self, quality):           # quality: [G, N]
+        if quality.numel() == 0:
+            raise ValueError("No ground-truth boxes or proposals available for one of the images during training")
+        vals, matches = quality.max(dim=0)
+        all_matches = matches.clone() if self.allow_low else None
+        matches[vals < self.low] = self.BELOW_LOW
+        matches[(vals >= self.low) & (vals < self.high)] = self.BETWEEN
+        if self.allow_low:
+            # every ground truth keeps the prediction(s) it overlaps best, however poorly
+            best_per_gt = quality.max(dim=1)[0]
+            restore = torch.where(quality == best_per_gt[:, None])[1]
+            matches[restore] = all_matches[restore]
+        return matches
+
+
+def sample_pos_neg(labels_per_image, batch_size, positive_fraction):
+    """Random subset of at most `batch_size` entries per image with up to `positive_fraction`
+    positives (label >= 1), rest negatives (label == 0).  Returns per-image index tensors."""
+    out = []
+    for labels in labels_per_image:
+        pos = torch.where(labels >= 1)[0]
+        neg = torch.where(labels == 0)[0]
+        n_pos = min(pos.numel(), int(batch_size * positive_fraction))
+        n_neg = min(neg.numel(), batch_size - n_pos)
+        pos = pos[torch.randperm(pos.numel(), device=pos.device)[:n_pos]]
+        neg = neg[torch.randperm(neg.numel(), device=neg.device)[:n_neg]]
+        out.append((pos, neg))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# NMS
+# ------------------------------------------------------------------------------------------------
+
+def _nms_torch(boxes, scores, thr):
+    order = scores.argsort(descending=True)
+    b = boxes[order]
+    n = b.shape[0]
+    if n == 0:
+        return order
+    suppress = torch.triu(box_iou(b, b) > thr, diagonal=1)
+    removed = torch.zeros(n, dtype=torch.bool, device=b.device)
+    keep = []
+    sup = suppress.cpu()
+    rem = removed.cpu()
+    for i in range(n):
+        if not rem[i]:
+            keep.append(i)
+            rem |= sup[i]
+    return order[torch.as_tensor(keep, dtype=torch.long, device=b.device)]
+
+
+def nms(boxes, scores, iou_threshold):
+    """Indices of the boxes that survive greedy NMS, by descending score."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    if not boxes.is_cuda:
+        return _nms_torch(boxes.float(), scores.float(), iou_threshold)
+    l = _lib.lib()
+    order = scores.argsort(descending=True)
+    b = boxes.float()[order].contiguous()
+    n = b.shape[0]
+    if n > 16384:
+        order, b, n = order[:16384], b[:16384].contiguous(), 16384
+    ws = torch.empty(l.dib_nms_workspace_bytes(n), dtype=torch.uint8, device=b.device)
+    keep = torch.empty(n, dtype=torch.int64, device=b.device)
+    count = torch.empty(1, dtype=torch.int32, device=b.device)
+    _lib.check(l.dib_nms(b.data_ptr(), n, float(iou_threshold), ws.data_ptr(), keep.data_ptr(), count.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream))
+    return order[keep[:int(count.item())]]
+
+
+def batched_nms(boxes, scores, groups, iou_threshold):
+    """NMS within each group (FPN level / class): boxes of different groups are moved apart."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    offsets = groups.to(boxes) * (boxes.max() + 1)
+    return nms(boxes + offsets[:, None], scores, iou_threshold)
+
+
+# ------------------------------------------------------------------------------------------------
+# RoIAlign
+# ------------------------------------------------------------------------------------------------
+
+def _bilinear_torch(feat, b, y, x):
+    """feat [N,C,H,W]; b [K] batch index; y, x [K, S] sample coordinates -> [K, C, S]"""
+    H, W = feat.shape[-2:]
+    outside = (y < -1) | (y > H) | (x < -1) | (x > W)
+    y = y.clamp(min=0)
+    x = x.clamp(min=0)
+    y0 = y.floor().long().clamp(max=H - 1)
+    x0 = x.floor().long().clamp(max=W - 1)
+    y1 = (y0 + 1).clamp(max=H - 1)
+    x1 = (x0 + 1).clamp(max=W - 1)
+    y = torch.where(y0 >= H - 1, y0.to(y), y)
+    x = torch.where(x0 >= W - 1, x0.to(x), x)
+    ly, lx = y - y0, x - x0
+    hy, hx = 1 - ly, 1 - lx
+    fb = feat[b]                                           # [K, C, H, W]
+    K, C = fb.shape[:2]
+    flat = fb.reshape(K, C, H * W)
+
+    def g(yy, xx):
+        return flat.gather(2, (yy * W + xx)[:, None, :].expand(K, C, -1))
+    v = (hy * hx)[:, None] * g(y0, x0) + (hy * lx)[:, None] * g(y0, x1) + (ly * hx)[:, None] * g(y1, x0) + (ly * lx)[:, None] * g(y1, x1)
+    return v * (~outside)[:, None].to(v)
+
+
+def roi_align_torch(feat, rois, spatial_scale, pooled, sampling_ratio, aligned=False):
+    """Plain-PyTorch fp32 RoIAlign (differentiable): the CPU path and the numerics reference."""
+    K = rois.shape[0]
+    C = feat.shape[1]
+    if K == 0:
+        return feat.new_zeros((0, C, pooled, pooled))
+    b = rois[:, 0].long()
+    off = 0.5 if aligned else 0.0
+    x1, y1, x2, y2 = (rois[:, i] * spatial_scale - off for i in (1, 2, 3, 4))
+    rw, rh = x2 - x1, y2 - y1
+    if not aligned:
+        rw, rh = rw.clamp(min=1.0), rh.clamp(min=1.0)
+    bw, bh = rw / pooled, rh / pooled
+    assert sampling_ratio > 0, "adaptive sampling is not restated in the torch path"
+    g = sampling_ratio
+    p = torch.arange(pooled, device=feat.device, dtype=feat.dtype)
+    s = (torch.arange(g, device=feat.device, dtype=feat.dtype) + 0.5) / g
+    ys = y1[:, None, None] + (p[None, :, None] + s[None, None, :]) * bh[:, None, None]       # [K, P, g]
+    xs = x1[:, None, None] + (p[None, :, None] + s[None, None, :]) * bw[:, None, None]
+    yy = ys[:, :, None, :, None].expand(K, pooled, pooled, g, g).reshape(K, -1)
+    xx = xs[:, None, :, None, :].expand(K, pooled, pooled, g, g).reshape(K, -1)
+    v = _bilinear_torch(feat, b, yy, xx).reshape(K, C, pooled, pooled, g * g)
+    return v.mean(dim=-1)
+
+
+class _RoIAlignHIP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, spatial_scale, pooled, sampling_ratio, aligned):
+        feat = feat.contiguous()
+        rois = rois.contiguous().float()
+        N, C, H, W = feat.shape
+        K = rois.shape[0]
+        out = torch.empty((K, C, pooled, pooled), dtype=torch.float32, device=feat.device)
+        _lib.check(_lib.lib().dib_roi_align_forward(feat.data_ptr(), rois.data_ptr(), K, C, H, W, float(spatial_scale), pooled,
+                                                    sampling_ratio, int(aligned), out.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream))
+        ctx.save_for_backward(rois)
+        ctx.meta = (tuple(feat.shape), float(spatial_scale), pooled, sampling_ratio, int(aligned))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (rois,) = ctx.saved_tensors
+        shape, scale, pooled, sr, aligned = ctx.meta
+        N, C, H, W = shape
+        grad = torch.zeros(shape, dtype=torch.float32, device=grad_out.device)
+        g = grad_out.contiguous().float()
+        _lib.check(_lib.lib().dib_roi_align_backward(g.data_ptr(), rois.data_ptr(), rois.shape[0], C, H, W, scale, pooled, sr,
+                                                     aligned, grad.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return grad, None, None, None, None, None
+
+
+def roi_align(feat, rois, spatial_scale, pooled, sampling_ratio, aligned=False):
+    """feat [N,C,H,W] fp32, rois [K,5] (batch index, x1, y1, x2, y2) -> [K,C,pooled,pooled]."""
+    if feat.is_cuda:
+        if feat.dtype != torch.float32:
+            return _RoIAlignHIP.apply(feat.float(), rois, spatial_scale, pooled, sampling_ratio, aligned).to(feat.dtype)
+        return _RoIAlignHIP.apply(feat, rois, spatial_scale, pooled, sampling_ratio, aligned)
+    return roi_align_torch(feat, rois.to(feat.dtype), spatial_scale, pooled, sampling_ratio, aligned)
+
+
+class MultiScaleRoIAlign(torch.nn.Module):
+    """FPN RoI pooling: each RoI is pooled from the level k = floor(4 + log2(sqrt(area) / 224))
+    clamped to the available levels (Lin et al., FPN, eq. 1), output `output_size`^2, `sampling_ratio`
+    samples per bin side."""
+
+    def __init__(self, featmap_names, output_size, sampling_ratio):
+        super().__init__()
+        self.featmap_names = featmap_names
+        self.output_size = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+        self.sampling_ratio = sampling_ratio
+
+    def forward(self, features, boxes, image_shapes):
+        feats = [features[k] for k in self.featmap_names if k in features]
+        ids = torch.cat([torch.full((b.shape[0], 1), i, dtype=b.dtype, device=b.device) for i, b in enumerate(boxes)], dim=0)
+        rois = torch.cat([ids, torch.cat(boxes, dim=0)], dim=1)
+        max_h = max(s[0] for s in image_shapes)
+        max_w = max(s[1] for s in image_shapes)
+        scales = []
+        for f in feats:
+            # spatial scale = 2^round(log2(feature / image)) as in torchvision's infer_scale
+            s = 2.0 ** round(math.log2(f.shape[-2] / float(max_h)))
+            s2 = 2.0 ** round(math.log2(f.shape[-1] / float(max_w)))
+            assert s == s2
+            scales.append(s)
+        P = self.output_size[0]
+        if len(feats) == 1:
+            return roi_align(feats[0], rois, scales[0], P, self.sampling_ratio)
+        k_min, k_max = -math.log2(scales[0]), -math.log2(scales[-1])
+        area = box_area(rois[:, 1:])
+        lvl = torch.floor(4 + torch.log2(torch.sqrt(area) / 224) + 1e-6).clamp(min=k_min, max=k_max).long() - int(k_min)
+        out = torch.zeros((rois.shape[0], feats[0].shape[1], P, P), dtype=feats[0].dtype, device=rois.device)
+        for i, (f, s) in enumerate(zip(feats, scales)):
+            idx = torch.where(lvl == i)[0]
+            if idx.numel():
+                out[idx] = roi_align(f, rois[idx], s, P, self.sampling_ratio).to(out.dtype)
+        return out

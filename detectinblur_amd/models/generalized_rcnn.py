@@ -1,0 +1,52 @@
+"""`GeneralizedRCNN` with the reference's extended forward signature (reference
+models/generalized_rcnn.py:78): per-image normalisation statistics travel with the call
+(`newMeans` / `newSTDs`); `thetas / lambda1s / lambda2s / killWarp` belong to the "squint" warper
+(`--warp_in_model`), which is out of scope here and therefore only accepted, not used.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+
+class GeneralizedRCNN(nn.Module):
+    def __init__(self, backbone, rpn, roi_heads, transform, warp_internally=False):
+        super().__init__()
+        if warp_internally:
+            raise NotImplementedError("--warp_in_model (models/warper.py) is outside the built hot path (SURVEY.md 8f)")
+        self.transform, self.backbone, self.rpn, self.roi_heads = transform, backbone, rpn, roi_heads
+        self.warp_internally = False
+
+    def forward(self, images, targets=None, thetas=None, lambda1s=None, lambda2s=None, killWarp=False, newMeans=None,
+                newSTDs=None):
+        if self.training and targets is None:
+            raise ValueError("In training mode, targets should be passed")
+        if self.training:
+            for target in targets:
+                boxes = target["boxes"]
+                if not isinstance(boxes, torch.Tensor):
+                    raise ValueError("Expected target boxes to be of type Tensor, got {:}.".format(type(boxes)))
+                if boxes.dim() != 2 or boxes.shape[-1] != 4:
+                    raise ValueError("Expected target boxes to be a tensor of shape [N, 4], got {:}.".format(boxes.shape))
+        original_sizes = [(int(img.shape[-2]), int(img.shape[-1])) for img in images]
+        images, targets = self.transform(images, targets, newMeans, newSTDs)
+        if targets is not None:
+            for idx, target in enumerate(targets):
+                boxes = target["boxes"]
+                bad = boxes[:, 2:] <= boxes[:, :2]
+                if bad.any():
+                    bb = boxes[bad.any(dim=1).nonzero().view(-1)[0]].tolist()
+                    raise ValueError("All bounding boxes should have positive height and width."
+                                     " Found invaid box {} for target at index {}.".format(bb, idx))
+        features = self.backbone(images.tensors)
+        if isinstance(features, torch.Tensor):
+            features = OrderedDict([("0", features)])
+        proposals, proposal_losses = self.rpn(images, features, targets)
+        detections, detector_losses = self.roi_heads(features, proposals, images.image_sizes, targets)
+        detections = self.transform.postprocess(detections, images.image_sizes, original_sizes)
+        if self.training:
+            losses = {}
+            losses.update(detector_losses)
+            losses.update(proposal_losses)
+            return losses
+        return detections

@@ -1,0 +1,159 @@
+"""Region proposal network of Faster R-CNN on FPN levels (Ren et al. 2015; Lin et al. 2017), with the
+hyper-parameters the reference passes to torchvision's RegionProposalNetwork
+(reference models/faster_rcnn.py:150-154, 185-203)."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import detector_ops as ops
+
+
+class AnchorGenerator(nn.Module):
+    def __init__(self, sizes=((32,), (64,), (128,), (256,), (512,)), aspect_ratios=((0.5, 1.0, 2.0),) * 5):
+        super().__init__()
+        self.sizes, self.aspect_ratios = sizes, aspect_ratios
+
+    def num_anchors_per_location(self):
+        return [len(s) * len(a) for s, a in zip(self.sizes, self.aspect_ratios)]
+
+    @staticmethod
+    def _base(scales, ratios, dtype, device):
+        scales = torch.as_tensor(scales, dtype=dtype, device=device)
+        ratios = torch.as_tensor(ratios, dtype=dtype, device=device)
+        h_r = torch.sqrt(ratios)
+        w_r = 1 / h_r
+        ws = (w_r[:, None] * scales[None, :]).view(-1)
+        hs = (h_r[:, None] * scales[None, :]).view(-1)
+        return (torch.stack([-ws, -hs, ws, hs], dim=1) / 2).round()
+
+    def forward(self, image_list, feature_maps):
+        img_h, img_w = image_list.tensors.shape[-2:]
+        dtype, device = feature_maps[0].dtype, feature_maps[0].device
+        per_level = []
+        for f, s, a in zip(feature_maps, self.sizes, self.aspect_ratios):
+            gh, gw = f.shape[-2:]
+            sh, sw = img_h // gh, img_w // gw
+            xs = torch.arange(0, gw, dtype=torch.float32, device=device) * sw
+            ys = torch.arange(0, gh, dtype=torch.float32, device=device) * sh
+            yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+            shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+            per_level.append((shifts[:, None, :] + self._base(s, a, dtype, device)[None]).reshape(-1, 4))
+        anchors = torch.cat(per_level)
+        return [anchors for _ in image_list.image_sizes]
+
+
+class RPNHead(nn.Module):
+    def __init__(self, in_channels, num_anchors):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, padding=1)
+        self.cls_logits = nn.Conv2d(in_channels, num_anchors, 1)
+        self.bbox_pred = nn.Conv2d(in_channels, num_anchors * 4, 1)
+        for l in self.children():
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+
+    def forward(self, feats):
+        logits, deltas = [], []
+        for f in feats:
+            t = F.relu(self.conv(f))
+            logits.append(self.cls_logits(t))
+            deltas.append(self.bbox_pred(t))
+        return logits, deltas
+
+
+def _flatten_levels(logits, deltas):
+    """per level [N, A, H, W] / [N, 4A, H, W] -> [N * sum(HWA), 1] / [N * sum(HWA), 4], level-major per image"""
+    ls, ds = [], []
+    for lg, dl in zip(logits, deltas):
+        N, A, H, W = lg.shape
+        ls.append(lg.permute(0, 2, 3, 1).reshape(N, -1, 1))
+        ds.append(dl.view(N, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, 4))
+    return torch.cat(ls, dim=1).flatten(0, -2), torch.cat(ds, dim=1).reshape(-1, 4)
+
+
+class RegionProposalNetwork(nn.Module):
+    def __init__(self, anchor_generator, head, fg_iou_thresh, bg_iou_thresh, batch_size_per_image, positive_fraction,
+                 pre_nms_top_n, post_nms_top_n, nms_thresh):
+        super().__init__()
+        self.anchor_generator = anchor_generator
+        self.head = head
+        self.box_coder = ops.BoxCoder((1.0, 1.0, 1.0, 1.0))
+        self.matcher = ops.Matcher(fg_iou_thresh, bg_iou_thresh, allow_low_quality_matches=True)
+        self.batch_size_per_image, self.positive_fraction = batch_size_per_image, positive_fraction
+        self._pre, self._post = pre_nms_top_n, post_nms_top_n
+        self.nms_thresh = nms_thresh
+        self.min_size = 1e-3
+
+    def _n(self, d):
+        return d["training"] if self.training else d["testing"]
+
+    def filter_proposals(self, proposals, objectness, image_sizes, counts):
+        N = proposals.shape[0]
+        objectness = objectness.detach().reshape(N, -1)
+        levels = torch.cat([torch.full((n,), i, dtype=torch.int64, device=proposals.device) for i, n in enumerate(counts)])
+        # top-k per level before NMS
+        idx, off = [], 0
+        for ob in objectness.split(counts, 1):
+            k = min(self._n(self._pre), ob.shape[1])
+            idx.append(ob.topk(k, dim=1)[1] + off)
+            off += ob.shape[1]
+        idx = torch.cat(idx, dim=1)
+        rows = torch.arange(N, device=proposals.device)[:, None]
+        objectness, levels, proposals = objectness[rows, idx], levels[None].expand(N, -1)[rows, idx], proposals[rows, idx]
+        boxes_out, scores_out = [], []
+        for boxes, scores, lvl, size in zip(proposals, objectness, levels, image_sizes):
+            boxes = ops.clip_boxes_to_image(boxes, size)
+            keep = ops.remove_small_boxes(boxes, self.min_size)
+            boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
+            keep = ops.batched_nms(boxes, scores, lvl, self.nms_thresh)[:self._n(self._post)]
+            boxes_out.append(boxes[keep])
+            scores_out.append(scores[keep])
+        return boxes_out, scores_out
+
+    def assign_targets(self, anchors, targets):
+        labels, matched = [], []
+        for a, t in zip(anchors, targets):
+            gt = t["boxes"]
+            if gt.numel() == 0:
+                matched.append(torch.zeros_like(a))
+                labels.append(torch.zeros((a.shape[0],), dtype=torch.float32, device=a.device))
+                continue
+            m = self.matcher(ops.box_iou(gt, a))
+            matched.append(gt[m.clamp(min=0)])
+            lab = (m >= 0).to(torch.float32)
+            lab[m == ops.Matcher.BELOW_LOW] = 0.0
+            lab[m == ops.Matcher.BETWEEN] = -1.0       # ignored by the sampler
+            labels.append(lab)
+        return labels, matched
+
+    def compute_loss(self, objectness, deltas, labels, regression_targets):
+        picks = ops.sample_pos_neg(labels, self.batch_size_per_image, self.positive_fraction)
+        offs, pos_all, all_idx = 0, [], []
+        for (pos, neg), lab in zip(picks, labels):
+            pos_all.append(pos + offs)
+            all_idx.append(torch.cat([pos, neg]) + offs)
+            offs += lab.numel()
+        pos_all, all_idx = torch.cat(pos_all), torch.cat(all_idx)
+        objectness = objectness.flatten()
+        labels, regression_targets = torch.cat(labels), torch.cat(regression_targets)
+        box_loss = F.smooth_l1_loss(deltas[pos_all], regression_targets[pos_all], beta=1 / 9, reduction="sum") / max(all_idx.numel(), 1)
+        obj_loss = F.binary_cross_entropy_with_logits(objectness[all_idx], labels[all_idx])
+        return obj_loss, box_loss
+
+    def forward(self, images, features, targets=None):
+        feats = list(features.values())
+        logits, deltas = self.head(feats)
+        anchors = self.anchor_generator(images, feats)
+        counts = [l[0].numel() for l in logits]
+        objectness, deltas = _flatten_levels(logits, deltas)
+        N = len(anchors)
+        proposals = self.box_coder.decode(deltas.detach(), torch.cat(anchors)).view(N, -1, 4)
+        boxes, _ = self.filter_proposals(proposals, objectness, images.image_sizes, counts)
+        losses = {}
+        if self.training:
+            assert targets is not None
+            labels, matched = self.assign_targets(anchors, targets)
+            reg_targets = [self.box_coder.encode(m, a) for m, a in zip(matched, anchors)]
+            obj, box = self.compute_loss(objectness, deltas, labels, reg_targets)
+            losses = {"loss_objectness": obj, "loss_rpn_box_reg": box}
+        return boxes, losses

@@ -96,3 +96,215 @@ def get_norm_params(blur_dicts, use_custom_image_norm):
 
 def collate_fn(batch):
     return tuple(zip(*batch))
+
+
+# ---------------------------------------------------------------------------------------------
+# distributed / logging helpers (reference utils.py:474-785)
+# ---------------------------------------------------------------------------------------------
+import datetime  # noqa: E402
+import errno  # noqa: E402
+import os  # noqa: E402
+import pickle  # noqa: E402
+import time  # noqa: E402
+from collections import defaultdict, deque  # noqa: E402
+
+import torch.distributed as dist  # noqa: E402
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def save_on_master(*args, **kwargs):
+    if is_main_process():
+        torch.save(*args, **kwargs)
+
+
+def mkdir(path):
+    try:
+        os.makedirs(path)
+    except OSError as e:
+        if e.errno != errno.EEXIST:
+            raise
+
+
+def setup_for_distributed(is_master):
+    """Only rank 0 prints (pass force=True to print anyway).  Reference utils.py:719-731."""
+    import builtins as __builtin__
+    builtin_print = __builtin__.print
+
+    def print(*args, **kwargs):
+        force = kwargs.pop("force", False)
+        if is_master or force:
+            builtin_print(*args, **kwargs)
+
+    __builtin__.print = print
+
+
+def init_distributed_mode(args):
+    """torchrun-style rendezvous: RANK / WORLD_SIZE / LOCAL_RANK from the environment, one process
+    per GPU.  Backend "nccl" IS RCCL on ROCm (xGMI inside a node); CPU-only hosts (tests) get gloo.
+    Reference utils.py:763-785 hard-codes 'nccl'."""
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        args.rank = int(os.environ["RANK"])
+        args.world_size = int(os.environ["WORLD_SIZE"])
+        args.gpu = int(os.environ.get("LOCAL_RANK", 0))
+    elif "SLURM_PROCID" in os.environ:
+        args.rank = int(os.environ["SLURM_PROCID"])
+        args.gpu = args.rank % max(torch.cuda.device_count(), 1)
+    else:
+        print("Not using distributed mode")
+        args.distributed = False
+        return
+    args.distributed = True
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(args.gpu)
+    args.dist_backend = "nccl" if use_gpu else "gloo"
+    print("| distributed init (rank {}): {}".format(args.rank, getattr(args, "dist_url", "env://")), flush=True)
+    kw = {}
+    if use_gpu:
+        kw["device_id"] = torch.device("cuda", args.gpu)
+    dist.init_process_group(backend=args.dist_backend, init_method=getattr(args, "dist_url", "env://"),
+                            world_size=args.world_size, rank=args.rank, **kw)
+    dist.barrier()
+    setup_for_distributed(args.rank == 0)
+
+
+def all_gather(data):
+    """Gathers arbitrary picklable objects from every rank (reference utils.py:536-576)."""
+    world_size = get_world_size()
+    if world_size == 1:
+        return [data]
+    out = [None] * world_size
+    dist.all_gather_object(out, data)
+    return out
+
+
+def reduce_dict(input_dict, average=True):
+    """All-reduces the values of a dict of scalar tensors (one stacked collective).  Reference
+    utils.py:579-603; used for logging only -- the gradients go through DDP's bucketed all-reduce."""
+    world_size = get_world_size()
+    if world_size < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        values = torch.stack([input_dict[k] for k in names], dim=0)
+        dist.all_reduce(values)
+        if average:
+            values /= world_size
+        return {k: v for k, v in zip(names, values)}
+
+
+class SmoothedValue(object):
+    """Windowed median / average plus the global average of a series (reference utils.py:474-533)."""
+
+    def __init__(self, window_size=20, fmt=None):
+        self.deque = deque(maxlen=window_size)
+        self.total, self.count = 0.0, 0
+        self.fmt = fmt or "{median:.4f} ({global_avg:.4f})"
+
+    def update(self, value, n=1):
+        self.deque.append(value)
+        self.count += n
+        self.total += value * n
+
+    def synchronize_between_processes(self):
+        if not is_dist_avail_and_initialized():
+            return
+        dev = "cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        dist.barrier()
+        dist.all_reduce(t)
+        self.count, self.total = int(t[0].item()), float(t[1].item())
+
+    @property
+    def median(self):
+        return torch.tensor(list(self.deque)).median().item()
+
+    @property
+    def avg(self):
+        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+
+    @property
+    def global_avg(self):
+        return self.total / max(self.count, 1)
+
+    @property
+    def max(self):
+        return max(self.deque)
+
+    @property
+    def value(self):
+        return self.deque[-1]
+
+    def __str__(self):
+        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
+
+
+class MetricLogger(object):
+    def __init__(self, delimiter="\t"):
+        self.meters = defaultdict(SmoothedValue)
+        self.delimiter = delimiter
+
+    def update(self, **kwargs):
+        for k, v in kwargs.items():
+            if isinstance(v, torch.Tensor):
+                v = v.item()
+            self.meters[k].update(v)
+
+    def __getattr__(self, attr):
+        if attr in self.meters:
+            return self.meters[attr]
+        raise AttributeError(attr)
+
+    def __str__(self):
+        return self.delimiter.join("{}: {}".format(n, str(m)) for n, m in self.meters.items())
+
+    def synchronize_between_processes(self):
+        for m in self.meters.values():
+            m.synchronize_between_processes()
+
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
+
+    def log_every(self, iterable, print_freq, header=None):
+        header = header or ""
+        start = end = time.time()
+        iter_time, data_time = SmoothedValue(fmt="{avg:.4f}"), SmoothedValue(fmt="{avg:.4f}")
+        n = len(iterable)
+        for i, obj in enumerate(iterable):
+            data_time.update(time.time() - end)
+            yield obj
+            iter_time.update(time.time() - end)
+            if i % print_freq == 0 or i == n - 1:
+                eta = str(datetime.timedelta(seconds=int(iter_time.global_avg * (n - i))))
+                msg = [header, "[{}/{}]".format(i, n), "eta: " + eta, str(self), "time: " + str(iter_time), "data: " + str(data_time)]
+                if torch.cuda.is_available():
+                    msg.append("max mem: {:.0f}".format(torch.cuda.max_memory_allocated() / (1024.0 * 1024.0)))
+                print(self.delimiter.join(msg))
+            end = time.time()
+        total = time.time() - start
+        print("{} Total time: {} ({:.4f} s / it)".format(header, str(datetime.timedelta(seconds=int(total))), total / max(n, 1)))
+
+
+def warmup_lr_scheduler(optimizer, warmup_iters, warmup_factor):
+    """Linear warm-up from warmup_factor to 1 over warmup_iters steps (reference utils.py:700-708)."""
+    def f(x):
+        if x >= warmup_iters:
+            return 1
+        alpha = float(x) / warmup_iters
+        return warmup_factor * (1 - alpha) + alpha
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, f)

@@ -110,6 +110,26 @@ int dib_psf_rasterize(const double *traj_dev, int B, int iters, const double *fr
                       int center, int out_n, double *psf64_dev, void *psf16_dev,
                       void *workspace_dev, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Detector ops the blurred batches feed (torchvision is not a dependency): RoIAlign as used by
+ * torchvision.ops.MultiScaleRoIAlign(output_size=7, sampling_ratio=2) (reference
+ * models/faster_rcnn.py:204-208) and NMS as used by RegionProposalNetwork / RoIHeads
+ * (reference models/faster_rcnn.py:198-229).  fp32, NCHW.
+ *   rois_dev: [K][5] = (batch index, x1, y1, x2, y2) in image coordinates.
+ *   dib_roi_align_backward ACCUMULATES into grad_feat_dev (caller zero-fills it first).
+ *   dib_nms: boxes [n][4] xyxy already sorted by descending score; keep_dev receives the kept
+ *   indices (ascending = score order), count_dev their number; workspace of dib_nms_workspace_bytes(n).
+ * ------------------------------------------------------------------------------------- */
+int dib_roi_align_forward(const float *feat_dev, const float *rois_dev, int K, int C, int H, int W,
+                          float spatial_scale, int pooled, int sampling_ratio, int aligned,
+                          float *out_dev, void *stream);
+int dib_roi_align_backward(const float *grad_out_dev, const float *rois_dev, int K, int C, int H,
+                           int W, float spatial_scale, int pooled, int sampling_ratio, int aligned,
+                           float *grad_feat_dev, void *stream);
+size_t dib_nms_workspace_bytes(int n);
+int dib_nms(const float *boxes_sorted_dev, int n, float iou_threshold, void *workspace_dev,
+            long long *keep_dev, int *count_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,117 @@
+"""Detector ops: the plain-PyTorch fp32 restatements against brute-force definitions (CPU), and the
+HIP kernels against the plain-PyTorch fp32 reference (GPU).  Tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from detectinblur_amd.models import detector_ops as ops
+
+
+def _brute_roi_align(feat, rois, scale, P, sr):
+    """Literal definition: average of sr x sr bilinear samples per bin (aligned=False)."""
+    K, C = rois.shape[0], feat.shape[1]
+    H, W = feat.shape[-2:]
+    out = torch.zeros(K, C, P, P, dtype=torch.float64)
+    f = feat.double()
+    for k in range(K):
+        b = int(rois[k, 0])
+        x1, y1, x2, y2 = [float(v) * scale for v in rois[k, 1:]]
+        rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
+        for ph in range(P):
+            for pw in range(P):
+                acc = torch.zeros(C, dtype=torch.float64)
+                for iy in range(sr):
+                    y = y1 + ph * rh / P + (iy + 0.5) * rh / P / sr
+                    for ix in range(sr):
+                        x = x1 + pw * rw / P + (ix + 0.5) * rw / P / sr
+                        if y < -1 or y > H or x < -1 or x > W:
+                            continue
+                        yy, xx = max(y, 0.0), max(x, 0.0)
+                        y0, x0 = int(yy), int(xx)
+                        if y0 >= H - 1:
+                            y0 = y1i = H - 1; yy = float(y0)
+                        else:
+                            y1i = y0 + 1
+                        if x0 >= W - 1:
+                            x0 = x1i = W - 1; xx = float(x0)
+                        else:
+                            x1i = x0 + 1
+                        ly, lx = yy - y0, xx - x0
+                        acc += (1 - ly) * (1 - lx) * f[b, :, y0, x0] + (1 - ly) * lx * f[b, :, y0, x1i] + ly * (1 - lx) * f[b, :, y1i, x0] + ly * lx * f[b, :, y1i, x1i]
+                out[k, :, ph, pw] = acc / (sr * sr)
+    return out
+
+
+def _rois(rs, n, N, H, W, scale):
+    x1 = rs.uniform(-5, W / scale - 4, n); y1 = rs.uniform(-5, H / scale - 4, n)
+    w = rs.uniform(0.3, W / scale * 0.7, n); h = rs.uniform(0.3, H / scale * 0.7, n)
+    return torch.tensor(np.stack([rs.randint(0, N, n), x1, y1, x1 + w, y1 + h], 1), dtype=torch.float32)
+
+
+def test_roi_align_torch_matches_definition():
+    rs = np.random.RandomState(0)
+    feat = torch.tensor(rs.randn(2, 3, 11, 13), dtype=torch.float32)
+    rois = _rois(rs, 9, 2, 11, 13, 0.25)
+    got = ops.roi_align_torch(feat, rois, 0.25, 7, 2)
+    want = _brute_roi_align(feat, rois, 0.25, 7, 2)
+    assert torch.allclose(got.double(), want, atol=1e-5)
+
+
+def test_nms_torch_matches_greedy_definition():
+    rs = np.random.RandomState(1)
+    c = rs.uniform(0, 100, (60, 2)); s = rs.uniform(5, 40, (60, 2))
+    boxes = torch.tensor(np.concatenate([c - s / 2, c + s / 2], 1), dtype=torch.float32)
+    scores = torch.tensor(rs.rand(60), dtype=torch.float32)
+    keep = ops.nms(boxes, scores, 0.4).tolist()
+    order = scores.argsort(descending=True).tolist()
+    want = []
+    for i in order:
+        if all(float(ops.box_iou(boxes[i:i + 1], boxes[j:j + 1])) <= 0.4 for j in want):
+            want.append(i)
+    assert keep == want
+
+
+def test_box_coder_roundtrip_and_matcher():
+    rs = np.random.RandomState(2)
+    a = torch.tensor(rs.uniform(0, 50, (20, 2)), dtype=torch.float32)
+    p = torch.cat([a, a + torch.tensor(rs.uniform(5, 30, (20, 2)), dtype=torch.float32)], 1)
+    g = p + torch.tensor(rs.uniform(-2, 2, (20, 4)), dtype=torch.float32)
+    coder = ops.BoxCoder((10., 10., 5., 5.))
+    assert torch.allclose(coder.decode(coder.encode(g, p), p)[:, 0], g, atol=1e-3)
+    q = torch.tensor([[0.9, 0.2, 0.1, 0.45], [0.1, 0.6, 0.2, 0.40]])
+    assert ops.Matcher(0.7, 0.3, False)(q.clone()).tolist() == [0, -2, -1, -2]
+    assert ops.Matcher(0.7, 0.3, True)(q.clone()).tolist() == [0, 1, -1, -2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,scale", [((2, 16, 50, 68), 0.25), ((1, 256, 25, 34), 0.125), ((3, 8, 7, 9), 1 / 32)])
+def test_roi_align_hip_forward_backward(shape, scale):
+    """HIP RoIAlign vs the plain-PyTorch fp32 reference: forward <= 1e-5 abs, backward <= 1e-4 abs
+    (fp32 atomics change the summation order)."""
+    rs = np.random.RandomState(3)
+    N, C, H, W = shape
+    feat = torch.tensor(rs.randn(*shape), dtype=torch.float32)
+    rois = _rois(rs, 37, N, H, W, scale)
+    f_ref = feat.clone().requires_grad_(True)
+    ref = ops.roi_align_torch(f_ref, rois, scale, 7, 2)
+    gout = torch.tensor(rs.randn(*ref.shape), dtype=torch.float32)
+    ref.backward(gout)
+    f_gpu = feat.cuda().requires_grad_(True)
+    out = ops.roi_align(f_gpu, rois.cuda(), scale, 7, 2)
+    out.backward(gout.cuda())
+    assert torch.allclose(out.cpu(), ref.detach(), atol=1e-5)
+    assert torch.allclose(f_gpu.grad.cpu(), f_ref.grad, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 700, 3000])
+def test_nms_hip_matches_torch(n):
+    rs = np.random.RandomState(n)
+    c = rs.uniform(0, 400, (n, 2)); s = rs.uniform(5, 80, (n, 2))
+    boxes = torch.tensor(np.concatenate([c - s / 2, c + s / 2], 1), dtype=torch.float32)
+    scores = torch.tensor(rs.permutation(n) / float(n), dtype=torch.float32)   # distinct scores: unique order
+    want = ops.nms(boxes, scores, 0.5)
+    got = ops.nms(boxes.cuda(), scores.cuda(), 0.5)
+    assert got.cpu().tolist() == want.tolist()
+    groups = torch.tensor(rs.randint(0, 3, n))
+    assert ops.batched_nms(boxes.cuda(), scores.cuda(), groups.cuda(), 0.5).cpu().tolist() == ops.batched_nms(boxes, scores, groups, 0.5).tolist()

@@ -1,0 +1,114 @@
+"""CPU tests of the detector, the engines and the multi-process path (gloo, world_size 2).
+The blur itself needs the GPU (no CPU path by design), so these run with blurring off or with
+pre-built blur_dicts; the GPU tests cover the blurred step."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _small_model():
+    from detectinblur_amd.models.faster_rcnn import fasterrcnn_resnet50_fpn
+    torch.manual_seed(0)
+    return fasterrcnn_resnet50_fpn(pretrained=False, pretrained_backbone=False, num_classes=91, min_size=96, max_size=128,
+                                   rpn_pre_nms_top_n_train=200, rpn_post_nms_top_n_train=100, rpn_post_nms_top_n_test=50,
+                                   box_batch_size_per_image=32)
+
+
+def test_detector_train_and_eval_cpu():
+    m = _small_model()
+    assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - 41.76) < 0.05      # R50-FPN Faster R-CNN, 91 classes
+    assert all(p.requires_grad for p in m.parameters())                          # trainable_layers = 5 without pretrained weights
+    imgs = [torch.rand(3, 90, 120), torch.rand(3, 96, 100)]
+    tg = [{"boxes": torch.tensor([[10., 20., 60., 70.]]), "labels": torch.tensor([3])},
+          {"boxes": torch.tensor([[5., 5., 50., 60.], [20., 30., 90., 80.]]), "labels": torch.tensor([1, 9])}]
+    before = tg[1]["boxes"].clone()
+    m.train()
+    import numpy as np
+    means = np.tile([0.485, 0.456, 0.406], (2, 1)); stds = np.tile([0.229, 0.224, 0.225], (2, 1))
+    losses = m(imgs, tg, newMeans=means, newSTDs=stds)
+    assert set(losses) == {"loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"}
+    assert all(torch.isfinite(v) for v in losses.values())
+    sum(losses.values()).backward()
+    assert torch.equal(tg[1]["boxes"], before)                                   # caller's targets untouched
+    with pytest.raises(ValueError, match="positive height and width"):
+        m(imgs, [{"boxes": torch.tensor([[10., 20., 10., 70.]]), "labels": torch.tensor([3])}, tg[1]])
+    with pytest.raises(ValueError, match="targets should be passed"):
+        m(imgs)
+    m.eval()
+    with torch.no_grad():
+        det = m(imgs)
+    assert len(det) == 2 and set(det[0]) == {"boxes", "labels", "scores"}
+
+
+def test_train_one_epoch_and_evaluate_cpu(tmp_path):
+    from detectinblur_amd import utils
+    from detectinblur_amd.coco_utils import SyntheticCocoDetection
+    from detectinblur_amd.engine import evaluate, get_network_index_to_use_blur_estimator_LEHE, get_network_index_to_use_oracle, train_one_epoch
+    from detectinblur_amd.train import get_transform
+    ds = SyntheticCocoDetection(num_images=4, size=(90, 120), boxes_per_image=3, transforms=get_transform(True))
+    for b in [ds[i][1]["boxes"] for i in range(4)]:
+        b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 8)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, collate_fn=utils.collate_fn)
+    m = _small_model()
+    opt = torch.optim.SGD(m.parameters(), lr=0.001, momentum=0.9)
+    w0 = m.roi_heads.box_predictor.cls_score.weight.clone()
+    log = train_one_epoch(m, opt, loader, torch.device("cpu"), epoch=0, print_freq=1, blur_train=False, early_stop=None)
+    assert not torch.equal(w0, m.roi_heads.box_predictor.cls_score.weight)
+    assert log.meters["loss"].count == 2
+    out = evaluate(m, torch.utils.data.DataLoader(ds, batch_size=1, collate_fn=utils.collate_fn), torch.device("cpu"), vanilla_eval=True)
+    assert len(out["detections"]) == 4
+    # routers (reference engine.py:171-218)
+    assert get_network_index_to_use_oracle([{"blurring": True, "param_index": 2, "fraction_index": 3}], [0, 1, 2, 3]) == 3
+    assert get_network_index_to_use_oracle([{"blurring": True, "param_index": 0, "fraction_index": -1}], [0, 1, 2, 3]) == 0
+    assert get_network_index_to_use_oracle([{"blurring": False, "param_index": None}], [0, 1, 2, 3]) == 0
+    assert get_network_index_to_use_blur_estimator_LEHE(torch.tensor([0.1, 0.2, 0.9, 0.3]), [0, 1, 2, 3]) == 2
+
+
+_DDP_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from detectinblur_amd import utils
+from tests.test_engine_ddp_cpu import _small_model
+class A: pass
+args = A(); args.dist_url = "env://"
+utils.init_distributed_mode(args)
+assert args.distributed and args.dist_backend == "gloo" and dist.get_world_size() == 2
+m = _small_model()
+ddp = torch.nn.parallel.DistributedDataParallel(m)
+rank = dist.get_rank()
+g = torch.Generator().manual_seed(100 + rank)
+imgs = [torch.rand(3, 90, 120, generator=g)]
+tg = [{"boxes": torch.tensor([[10. + rank, 20., 60., 70.]]), "labels": torch.tensor([3 + rank])}]
+ddp.train()
+torch.manual_seed(5)             # same sampling decisions on both ranks
+losses = ddp(imgs, tg)
+red = utils.reduce_dict(losses)
+sum(losses.values()).backward()
+# after DDP's all-reduce every rank holds the same (averaged) gradient
+gsum = torch.cat([p.grad.flatten()[:50] for p in m.parameters() if p.grad is not None][:5])
+out = [torch.zeros_like(gsum) for _ in range(2)]
+dist.all_gather(out, gsum)
+assert torch.allclose(out[0], out[1]), "gradients differ across ranks"
+got = utils.all_gather({"rank": rank})
+assert [d["rank"] for d in got] == [0, 1]
+vals = [torch.zeros(1) for _ in range(2)]
+dist.all_gather(vals, red["loss_classifier"].detach().reshape(1))
+assert torch.allclose(vals[0], vals[1])
+print("rank", rank, "ok", flush=True, force=True)
+dist.destroy_process_group()
+'''
+
+
+def test_ddp_gloo_world_size_2(tmp_path):
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_SCRIPT % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
