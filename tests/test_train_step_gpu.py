@@ -1,0 +1,69 @@
+"""GPU integration: one blurred training step and one blurred evaluation pass through the engines
+(`--blur_train --gpu_blur --expand_target_boxes`), exactly the call sequence of reference engine.py:74-158."""
+import numpy as np
+import pytest
+import torch
+
+import dib_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    from detectinblur_amd.models.faster_rcnn import fasterrcnn_resnet50_fpn
+    torch.manual_seed(0)
+    return fasterrcnn_resnet50_fpn(pretrained=False, pretrained_backbone=False, num_classes=91, min_size=160, max_size=224,
+                                   rpn_pre_nms_top_n_train=400, rpn_post_nms_top_n_train=200, rpn_post_nms_top_n_test=100).cuda()
+
+
+def _loader(train, n=4):
+    import random
+    from detectinblur_amd import utils
+    from detectinblur_amd.coco_utils import SyntheticCocoDetection
+    from detectinblur_amd.train import get_transform
+    random.seed(3); np.random.seed(3)
+    tf = get_transform(train, blur=True, blur_type=0.005, blur_ratio=1.0, low_exposure=True)
+    ds = SyntheticCocoDetection(num_images=n, size=(150, 210), boxes_per_image=4, transforms=tf)
+    return torch.utils.data.DataLoader(ds, batch_size=2 if train else 1, collate_fn=utils.collate_fn)
+
+
+def test_blurred_train_step_and_eval():
+    from detectinblur_amd.engine import evaluate, train_one_epoch
+    m = _model()
+    opt = torch.optim.SGD(m.parameters(), lr=0.002, momentum=0.9)
+    w0 = m.backbone.body.conv1.weight.detach().clone()
+    log = train_one_epoch(m, opt, _loader(True), torch.device("cuda"), epoch=0, print_freq=1, blur_train=True, gpu_blur=True,
+                          expand_target_boxes=True, use_custom_image_norm=True, early_stop=None)
+    assert log.meters["loss"].count == 2 and np.isfinite(log.meters["loss"].global_avg)
+    assert not torch.equal(w0, m.backbone.body.conv1.weight.detach())
+    out = evaluate(m, _loader(False), torch.device("cuda"), blurring_images=True, gpu_blur=True, expand_target_boxes=True)
+    assert len(out["detections"]) == 4
+
+
+def test_engine_blur_equals_oracle_on_loader_batch():
+    """What the engine feeds the detector is bit-identical to the oracle's blur of the same batch."""
+    from detectinblur_amd import engine, utils
+    from detectinblur_amd.models import blur_functions
+    images_CPU, targets, blur_dicts = next(iter(_loader(True)))
+    imgs, tg, psfs, *_ = engine._to_device(images_CPU, targets, blur_dicts, torch.device("cuda"), True)
+    want_imgs = [i.half().numpy().copy() for i in images_CPU]
+    want_psfs = [O.to_half_like_torch(bd["psf"]) for bd in blur_dicts]
+    O.blur_image_list(want_imgs, blur_dicts, want_psfs)
+    want_boxes = [O.expand_boxes(t["boxes"].numpy(), p, i.shape[1], i.shape[2]) for t, p, i in zip(targets, want_psfs, images_CPU)]
+    blur_functions.blur_image_list(imgs, blur_dicts, psfs_GPU=psfs)
+    tg = utils.expand_targets(tg, blur_dicts, psfs, imgs)
+    for g, w in zip(imgs, want_imgs):
+        assert np.array_equal(g.cpu().numpy().view(np.uint16), w.view(np.uint16))
+    for t, w in zip(tg, want_boxes):
+        assert np.array_equal(t["boxes"].cpu().numpy(), w)
+
+
+def test_ensemble_routing_runs():
+    from torch import nn
+    from detectinblur_amd.engine import evaluate
+    from detectinblur_amd.models.blur_estimator import resnet18
+    nets = [_model() for _ in range(2)] * 2
+    est = resnet18(); est.fc = nn.Linear(512, 4); est = est.cuda()
+    out = evaluate(None, _loader(False, 2), torch.device("cuda"), blurring_images=True, gpu_blur=True, expand_target_boxes=True,
+                   use_ensemble=True, ensemble_models=nets, blur_estimator=est, LEHE=True)
+    assert len(out["routes"]) == 2 and all(r in (0, 1, 2, 3) for r in out["routes"])
