@@ -31,6 +31,8 @@ _SIGNATURES = {
     "dib_tap_tables_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "dib_psf_compact": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_psf_compact_list": (ctypes.c_int, [_c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_void_p]),
     "dib_sparse_blur": (ctypes.c_int, [_c_void_pp, _c_void_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p]),

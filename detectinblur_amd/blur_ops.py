@@ -65,11 +65,29 @@ class TapTables:
 
 
 def compact_psfs(psfs, normalize):
-    """psfs: list of K x K tensors (same K, same dtype) or one [B,K,K] tensor -> TapTables."""
+    """psfs: list of K x K tensors (same K, same dtype) or one [B,K,K] tensor -> TapTables.
+    A list is passed as device pointers (no stacking copy)."""
+    l = _lib.lib()
     if isinstance(psfs, (list, tuple)):
-        stack = psfs[0].unsqueeze(0) if len(psfs) == 1 else torch.stack(list(psfs))
-    else:
-        stack = psfs
+        first = psfs[0]
+        _require_cuda(first, "PSF")
+        K, dt = first.shape[0], first.dtype
+        if dt not in _DT:
+            raise TypeError("PSF dtype %s not supported (float16 / float32)" % dt)
+        keep = []
+        for p in psfs:
+            if p.dim() != 2 or p.shape[0] != K or p.shape[1] != K or p.dtype != dt or not p.is_cuda:
+                raise ValueError("all PSFs of one call must be K x K CUDA tensors of one dtype")
+            p = p.contiguous()
+            if p.data_ptr() % 16:
+                p = p.clone()
+            keep.append(p)
+        tabs = TapTables(K, len(keep), first.device)
+        tabs._pin = keep   # alive until the tables die
+        _lib.check(l.dib_psf_compact_list(_lib.ptr_array([p.data_ptr() for p in keep]), _DT[dt], len(keep), K,
+                                          int(bool(normalize)), tabs.buf.data_ptr(), _stream()))
+        return tabs
+    stack = psfs
     _require_cuda(stack, "PSF")
     stack = stack.contiguous()
     if stack.dim() != 3 or stack.shape[1] != stack.shape[2]:
@@ -78,8 +96,8 @@ def compact_psfs(psfs, normalize):
         raise TypeError("PSF dtype %s not supported (float16 / float32)" % stack.dtype)
     B, K = stack.shape[0], stack.shape[1]
     tabs = TapTables(K, B, stack.device)
-    _lib.check(_lib.lib().dib_psf_compact(stack.data_ptr(), _DT[stack.dtype], B, K, int(bool(normalize)),
-                                          tabs.buf.data_ptr(), _stream()))
+    _lib.check(l.dib_psf_compact(stack.data_ptr(), _DT[stack.dtype], B, K, int(bool(normalize)),
+                                 tabs.buf.data_ptr(), _stream()))
     return tabs
 
 

@@ -13,6 +13,7 @@
 // owns K*K/1024 CONSECUTIVE elements, so thread order is element order.
 #include "dib_common.h"
 #include <hip/hip_fp16.h>
+#include <vector>
 
 namespace dib {
 
@@ -73,9 +74,12 @@ template <typename A> __device__ inline A wave_sum(A v) {
 constexpr int CT = 1024;          // threads per PSF
 constexpr int STAGE_TAPS = 4096;  // (row<<8|col) of the first taps are staged in LDS for the segmenter
 
+// PSF pointers travel by value in the kernel-argument buffer: a batch whose PSFs live in separate
+// tensors (the reference's `psfs_GPU` list, engine.py:84) needs no torch.stack copy.
+struct PsfPtrs { const void *p[MAX_BATCH]; };
+
 template <typename T, int K>
-__global__ __launch_bounds__(CT) void psf_compact_kernel(const T *__restrict__ psf, int normalize,
-                                                         int *__restrict__ tables) {
+__global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int normalize, int *__restrict__ tables) {
   using E = Elem<T>;
   constexpr int N = K * K, EPT = N / CT, LK = (K == 128) ? 7 : 8, NWAVE = CT / 64;
   __shared__ typename E::Acc s_part[NWAVE];
@@ -86,11 +90,11 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(const T *__restrict__ p
   __shared__ unsigned short s_w16[STAGE_TAPS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const T *p = psf + (size_t)blockIdx.x * N + (size_t)tid * EPT;
+  const T *p = reinterpret_cast<const T *>(ptrs.p[blockIdx.x]) + (size_t)tid * EPT;
   int *tab = tables + (size_t)blockIdx.x * table_words(K);
 
   // scheduler trailer behind the last table: the blur's tile-queue tickets start from zero
-  if (blockIdx.x == 0 && tid < SCHED_WORDS) tables[(size_t)gridDim.x * table_words(K) + tid] = 0;
+  if (blockIdx.x == 0 && tid < SCHED_WORDS && (normalize & 8)) tables[(size_t)gridDim.x * table_words(K) + tid] = 0;
 
   // ---- one vectorised read of this thread's EPT consecutive elements ---------------------------
   T v[EPT];
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(const T *__restrict__ p
 
   // ---- sum ------------------------------------------------------------------------------------
   T total = T(1.0f);
-  if (normalize) {
+  if (normalize & 1) {
     typename E::Acc acc = 0;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) acc += E::lift(v[i]);
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(const T *__restrict__ p
   const int e0 = tid * EPT;
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
-    if (normalize) v[i] = E::div(v[i], total);
+    if (normalize & 1) v[i] = E::div(v[i], total);
     if (E::nonzero(v[i])) {
       mask |= 1ull << i;
       const int r = (e0 + i) >> LK, c = (e0 + i) & (K - 1);
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(const T *__restrict__ p
   __threadfence_block();
   __syncthreads();
   if (wave != 0) return;
+  if (normalize & 4) return;  // diagnostics: skip the segmentation
 
   // ---- segmentation (wave 0): greedy runs with row span <= SEG_ROWS and column span <= SEG_COLS --------
   uint4 *segs = reinterpret_cast<uint4 *>(tab + table_segs_off(K));
@@ -255,19 +260,46 @@ extern "C" size_t dib_tap_tables_bytes(int K, int B) {
   return ((size_t)dib::table_words(K) * B + dib::SCHED_WORDS) * sizeof(int);
 }
 
-extern "C" int dib_psf_compact(const void *psf_dev, int dtype, int B, int K, int normalize, void *tables_dev,
-                               void *stream) {
-  if (!psf_dev || !tables_dev || B < 0) { dib::set_error("dib_psf_compact: null pointer or negative batch"); return DIB_EINVAL; }
-  if (K != 128 && K != 256) { dib::set_error("dib_psf_compact: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
-  if (dtype != DIB_F16 && dtype != DIB_F32) { dib::set_error("dib_psf_compact: unknown dtype %d", dtype); return DIB_EINVAL; }
-  if (((uintptr_t)psf_dev & 15) != 0) { dib::set_error("dib_psf_compact: PSF pointer must be 16-byte aligned"); return DIB_EINVAL; }
-  if (B == 0) return DIB_OK;
-  hipStream_t s = (hipStream_t)stream;
-  int *t = (int *)tables_dev;
-  if (dtype == DIB_F16 && K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 128>), dim3(B), dim3(dib::CT), 0, s, (const __half *)psf_dev, normalize, t);
-  else if (dtype == DIB_F16) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 256>), dim3(B), dim3(dib::CT), 0, s, (const __half *)psf_dev, normalize, t);
-  else if (K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<float, 128>), dim3(B), dim3(dib::CT), 0, s, (const float *)psf_dev, normalize, t);
-  else hipLaunchKernelGGL((dib::psf_compact_kernel<float, 256>), dim3(B), dim3(dib::CT), 0, s, (const float *)psf_dev, normalize, t);
+static int launch_compact(const void *const *ptrs, int dtype, int B, int K, int normalize, int *tables, hipStream_t s) {
+  const size_t stride = (size_t)dib::table_words(K);
+  for (int b0 = 0; b0 < B; b0 += dib::MAX_BATCH) {
+    dib::PsfPtrs pp;
+    const int n = B - b0 < dib::MAX_BATCH ? B - b0 : dib::MAX_BATCH;
+    for (int i = 0; i < n; ++i) {
+      if (!ptrs[b0 + i] || ((uintptr_t)ptrs[b0 + i] & 15) != 0) { dib::set_error("dib_psf_compact: PSF %d is null or not 16-byte aligned", b0 + i); return DIB_EINVAL; }
+      pp.p[i] = ptrs[b0 + i];
+    }
+    int *t = tables + (size_t)b0 * stride;
+    // bit 3: this launch owns the scheduler trailer behind the LAST table (only the final chunk does)
+    const int flags = (normalize ? 1 : 0) | ((b0 + n == B) ? 8 : 0);
+    if (dtype == DIB_F16 && K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 128>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
+    else if (dtype == DIB_F16) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 256>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
+    else if (K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<float, 128>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
+    else hipLaunchKernelGGL((dib::psf_compact_kernel<float, 256>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
+  }
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
+}
+
+static int check_compact_args(const void *p, void *tables_dev, int dtype, int B, int K) {
+  if (!p || !tables_dev || B < 0) { dib::set_error("dib_psf_compact: null pointer or negative batch"); return DIB_EINVAL; }
+  if (K != 128 && K != 256) { dib::set_error("dib_psf_compact: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
+  if (dtype != DIB_F16 && dtype != DIB_F32) { dib::set_error("dib_psf_compact: unknown dtype %d", dtype); return DIB_EINVAL; }
+  return DIB_OK;
+}
+
+extern "C" int dib_psf_compact(const void *psf_dev, int dtype, int B, int K, int normalize, void *tables_dev, void *stream) {
+  int rc = check_compact_args(psf_dev, tables_dev, dtype, B, K);
+  if (rc != DIB_OK || B == 0) return rc;
+  const size_t bytes = (size_t)K * K * (dtype == DIB_F16 ? 2 : 4);
+  std::vector<const void *> ptrs((size_t)B);
+  for (int i = 0; i < B; ++i) ptrs[i] = (const char *)psf_dev + (size_t)i * bytes;
+  return launch_compact(ptrs.data(), dtype, B, K, normalize, (int *)tables_dev, (hipStream_t)stream);
+}
+
+extern "C" int dib_psf_compact_list(const void *const *psf_ptrs, int dtype, int B, int K, int normalize, void *tables_dev,
+                                    void *stream) {
+  int rc = check_compact_args(psf_ptrs, tables_dev, dtype, B, K);
+  if (rc != DIB_OK || B == 0) return rc;
+  return launch_compact(psf_ptrs, dtype, B, K, normalize, (int *)tables_dev, (hipStream_t)stream);
 }

@@ -69,6 +69,10 @@ size_t dib_tap_tables_bytes(int K, int B);
  * zeroed scheduler trailer. */
 int dib_psf_compact(const void *psf_dev, int dtype, int B, int K, int normalize,
                     void *tables_dev, void *stream);
+/* same, for PSFs that live in B separate device buffers (host array of B device pointers, each
+ * 16-byte aligned): the reference's `psfs_GPU` list needs no stacking copy */
+int dib_psf_compact_list(const void *const *psf_ptrs, int dtype, int B, int K, int normalize,
+                         void *tables_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sparse PSF (x) image correlation: models/blur_functions.py:11-69 (`manual_blur`, both canvas

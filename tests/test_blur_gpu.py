@@ -271,3 +271,31 @@ def test_kernel_variants_are_bit_identical():
                 assert np.array_equal(_bits(g.cpu().numpy().squeeze()), _bits(w)), (nw, tpw)
     finally:
         l.dib_debug_set_variant(4, 1)
+
+
+def test_compaction_more_than_one_launch_chunk():
+    """40 PSFs = two compaction launches (32 + 8): list and stacked entry points agree, and the
+    scheduler trailer behind the last table is zeroed without touching any table."""
+    from detectinblur_amd import blur_ops
+    rs = np.random.RandomState(21)
+    psfs = []
+    for k in range(40):
+        a = np.zeros((128, 128), np.float16)
+        n = 5 + k
+        a[rs.randint(40, 90, n), rs.randint(40, 90, n)] = (rs.random_sample(n) + 0.1).astype(np.float16)
+        psfs.append(a)
+    t_list = blur_ops.compact_psfs([_dev(a) for a in psfs], normalize=True)
+    t_stack = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=True)
+    for k in range(40):       # only the defined part of a table is comparable (the rest is torch.empty)
+        assert t_list.header(k) == t_stack.header(k)
+        for a, b in zip(t_list.taps(k), t_stack.taps(k)):
+            assert torch.equal(a, b)
+        assert t_list.segments(k) == t_stack.segments(k)
+        for a, b in zip(t_list.ltaps(k), t_stack.ltaps(k)):
+            assert torch.equal(a, b)
+    for k in (0, 31, 32, 39):
+        rr, cc, ww = O.taps_of(O.normalize_psf(psfs[k]))
+        r, c, w = t_list.taps(k)
+        assert np.array_equal(r.numpy(), rr) and np.array_equal(c.numpy(), cc)
+        assert np.array_equal((w.numpy() & 0xffff).astype(np.uint16), ww.view(np.uint16))
+    assert int(t_list.buf[-256:].abs().sum()) == 0
