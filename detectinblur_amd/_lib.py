@@ -49,6 +49,12 @@ _SIGNATURES = {
     "dib_roi_align_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_roi_align_nhwc_forward": (ctypes.c_int, [_c_void_pp, _c_int_p, _c_int_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_roi_align_nhwc_backward": (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, ctypes.POINTER(ctypes.c_float),
+                                                   ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_void_pp, ctypes.c_void_p]),
     "dib_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "dib_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                ctypes.c_void_p, ctypes.c_void_p]),

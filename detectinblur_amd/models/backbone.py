@@ -28,10 +28,29 @@ class FrozenBatchNorm2d(nn.Module):
         state_dict.pop(prefix + "num_batches_tracked", None)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, x):
+    def affine(self):
         scale = self.weight * (self.running_var + self.eps).rsqrt()
-        shift = self.bias - self.running_mean * scale
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.affine()
         return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+# A frozen batch-norm behind a convolution is a per-output-channel affine map, so it folds into the
+# convolution: conv(x, w) * s + t == conv(x, w * s) + t.  The fold is recomputed from the live weight
+# every call (a few M elements), so gradients reach `conv.weight` unchanged in value up to fp32
+# rounding, and two full-activation elementwise passes per layer (forward) and one (backward)
+# disappear from the step.  Set to False to run the unfused module-by-module form.
+FOLD_FROZEN_BN = True
+
+
+def conv_bn(x, conv, bn):
+    if FOLD_FROZEN_BN and isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
+        scale, shift = bn.affine()
+        return F.conv2d(x, conv.weight * scale.reshape(-1, 1, 1, 1), shift, conv.stride, conv.padding, conv.dilation,
+                        conv.groups)
+    return bn(conv(x))
 
 
 class Bottleneck(nn.Module):
@@ -48,10 +67,10 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = F.relu(self.bn1(self.conv1(x)))
-        out = F.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        idt = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
+        out = F.relu(conv_bn(x, self.conv1, self.bn1))
+        out = F.relu(conv_bn(out, self.conv2, self.bn2))
+        out = conv_bn(out, self.conv3, self.bn3)
         return F.relu(out + idt)
 
 
@@ -77,7 +96,7 @@ class ResNet50Body(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        x = F.max_pool2d(F.relu(conv_bn(x, self.conv1, self.bn1)), 3, stride=2, padding=1)
         c2 = self.layer1(x)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)

@@ -6,6 +6,7 @@ fp32 reference used by the numerics tests -- they run the plain-PyTorch restatem
 Semantics: torchvision.ops.{roi_align(aligned=False), nms, batched_nms, box_iou, clip_boxes_to_image,
 remove_small_boxes}, which the reference's RPN / RoIHeads call (reference models/faster_rcnn.py:7-16).
 """
+import ctypes
 import math
 
 import torch
@@ -248,8 +249,51 @@ class _RoIAlignHIP(torch.autograd.Function):
         return grad, None, None, None, None, None
 
 
+def _is_nhwc(f):
+    return (f.is_cuda and f.dtype == torch.float32 and f.dim() == 4 and f.shape[1] > 1
+            and f.is_contiguous(memory_format=torch.channels_last))
+
+
+class _RoIAlignNHWC(torch.autograd.Function):
+    """Channels-last RoIAlign over 1..4 pyramid levels in one launch (include/dib.h:
+    dib_roi_align_nhwc_forward / _backward); `level` is a device int32 [K] tensor."""
+
+    @staticmethod
+    def forward(ctx, rois, level, scales, pooled, sampling_ratio, aligned, *feats):
+        rois = rois.contiguous().float()
+        K, C = rois.shape[0], feats[0].shape[1]
+        hs, ws = _lib.int_array([f.shape[2] for f in feats]), _lib.int_array([f.shape[3] for f in feats])
+        sc = (ctypes.c_float * len(feats))(*[float(s) for s in scales])
+        out = torch.empty((K, C, pooled, pooled), dtype=torch.float32, device=rois.device)
+        _lib.check(_lib.lib().dib_roi_align_nhwc_forward(
+            _lib.ptr_array([f.data_ptr() for f in feats]), hs, ws, sc, len(feats), rois.data_ptr(),
+            level.data_ptr() if level is not None else None, K, C, pooled, sampling_ratio, int(aligned), out.data_ptr(),
+            torch.cuda.current_stream().cuda_stream))
+        ctx.save_for_backward(rois, level) if level is not None else ctx.save_for_backward(rois)
+        ctx.meta = ([tuple(f.shape) for f in feats], [float(s) for s in scales], pooled, sampling_ratio, int(aligned))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        saved = ctx.saved_tensors
+        rois, level = saved[0], (saved[1] if len(saved) > 1 else None)
+        shapes, scales, pooled, sr, aligned = ctx.meta
+        grads = [torch.empty(sh, dtype=torch.float32, device=grad_out.device, memory_format=torch.channels_last).zero_()
+                 for sh in shapes]
+        g = grad_out.contiguous().float()
+        hs, ws = _lib.int_array([sh[2] for sh in shapes]), _lib.int_array([sh[3] for sh in shapes])
+        sc = (ctypes.c_float * len(shapes))(*scales)
+        _lib.check(_lib.lib().dib_roi_align_nhwc_backward(
+            g.data_ptr(), hs, ws, sc, len(shapes), rois.data_ptr(), level.data_ptr() if level is not None else None,
+            rois.shape[0], shapes[0][1], pooled, sr, aligned, _lib.ptr_array([x.data_ptr() for x in grads]),
+            torch.cuda.current_stream().cuda_stream))
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
 def roi_align(feat, rois, spatial_scale, pooled, sampling_ratio, aligned=False):
     """feat [N,C,H,W] fp32, rois [K,5] (batch index, x1, y1, x2, y2) -> [K,C,pooled,pooled]."""
+    if _is_nhwc(feat) and pooled <= 7:
+        return _RoIAlignNHWC.apply(rois, None, [spatial_scale], pooled, sampling_ratio, aligned, feat)
     if feat.is_cuda:
         if feat.dtype != torch.float32:
             return _RoIAlignHIP.apply(feat.float(), rois, spatial_scale, pooled, sampling_ratio, aligned).to(feat.dtype)
@@ -287,6 +331,9 @@ class MultiScaleRoIAlign(torch.nn.Module):
         k_min, k_max = -math.log2(scales[0]), -math.log2(scales[-1])
         area = box_area(rois[:, 1:])
         lvl = torch.floor(4 + torch.log2(torch.sqrt(area) / 224) + 1e-6).clamp(min=k_min, max=k_max).long() - int(k_min)
+        if len(feats) <= 4 and P <= 7 and all(_is_nhwc(f) for f in feats):
+            # channels-last pyramid: every level in one launch, no per-level index_select / scatter / host sync
+            return _RoIAlignNHWC.apply(rois, lvl.to(torch.int32), scales, P, self.sampling_ratio, False, *feats)
         out = torch.zeros((rois.shape[0], feats[0].shape[1], P, P), dtype=feats[0].dtype, device=rois.device)
         for i, (f, s) in enumerate(zip(feats, scales)):
             idx = torch.where(lvl == i)[0]

@@ -3,6 +3,7 @@
 `pretrained` / `pretrained_backbone` raise; random initialisation trains every backbone layer, as in
 the reference when neither is set (:361-363).
 """
+import torch
 from .backbone import resnet_fpn_backbone
 from .detector_ops import MultiScaleRoIAlign
 from .generalized_rcnn import GeneralizedRCNN
@@ -57,11 +58,18 @@ class FasterRCNN(GeneralizedRCNN):
 
 
 def fasterrcnn_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pretrained_backbone=True,
-                            trainable_backbone_layers=3, **kwargs):
+                            trainable_backbone_layers=3, channels_last=True, **kwargs):
     assert 0 <= trainable_backbone_layers <= 5
     if pretrained or pretrained_backbone:
         raise RuntimeError("pretrained weights cannot be downloaded here (no network); build with pretrained=False, "
                            "pretrained_backbone=False and load a state_dict (torchvision key layout is kept)")
     trainable_backbone_layers = 5      # nothing is frozen without pretrained weights (reference :361-363)
     backbone = resnet_fpn_backbone("resnet50", False, trainable_layers=trainable_backbone_layers)
-    return FasterRCNN(backbone, num_classes, **kwargs)
+    model = FasterRCNN(backbone, num_classes, **kwargs)
+    if channels_last:
+        # MI355X: MIOpen's fp32 implicit-GEMM convolutions are NHWC kernels (planar tensors pay a
+        # transpose around each), and the NHWC RoIAlign issues one atomic per 64 contiguous channels.
+        # Values, state_dict keys and shapes are unchanged; only the strides differ.
+        model = model.to(memory_format=torch.channels_last)
+        model.transform.channels_last = True
+    return model

@@ -68,17 +68,21 @@ class GeneralizedRCNNTransform(nn.Module):
             size = [min(s[i] for s in shapes) for i in range(3)]
             size[1] = int(math.floor(size[1] / stride) * stride)
             size[2] = int(math.floor(size[2] / stride) * stride)
-            out = images[0].new_zeros([len(images)] + size)
+            out = self._new_batch(images[0], [len(images)] + size)
             for img, dst in zip(images, out):
                 dst.copy_(img[:size[0], :size[1], :size[2]])
             return out
         size = [max(s[i] for s in shapes) for i in range(3)]
         size[1] = int(math.ceil(size[1] / stride) * stride)
         size[2] = int(math.ceil(size[2] / stride) * stride)
-        out = images[0].new_zeros([len(images)] + size)
+        out = self._new_batch(images[0], [len(images)] + size)
         for img, dst in zip(images, out):
             dst[:img.shape[0], :img.shape[1], :img.shape[2]].copy_(img)
         return out
+
+    def _new_batch(self, like, shape):
+        fmt = torch.channels_last if getattr(self, "channels_last", False) else torch.contiguous_format
+        return torch.empty(shape, dtype=like.dtype, device=like.device, memory_format=fmt).zero_()
 
     def forward(self, images, targets=None, newMeans=None, newSTDs=None):
         images = list(images)

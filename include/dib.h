@@ -130,6 +130,17 @@ int dib_roi_align_forward(const float *feat_dev, const float *rois_dev, int K, i
 int dib_roi_align_backward(const float *grad_out_dev, const float *rois_dev, int K, int C, int H,
                            int W, float spatial_scale, int pooled, int sampling_ratio, int aligned,
                            float *grad_feat_dev, void *stream);
+ /* Channels-last (NHWC) form over 1..4 pyramid levels in ONE launch: MultiScaleRoIAlign without the
+ * per-level index_select / scatter (and their host syncs).  feat_dev / grad_feat_dev: host arrays of
+ * n_levels device pointers to [N][H_l][W_l][C] fp32; H, W, scale: host arrays [n_levels];
+ * level_dev: device int32 [K], the level of each RoI (may be NULL when n_levels == 1);
+ * out / grad_out: [K][C][pooled][pooled] contiguous, as above.  pooled <= 7. */
+int dib_roi_align_nhwc_forward(const float *const *feat_dev, const int *H, const int *W, const float *scale,
+                               int n_levels, const float *rois_dev, const int *level_dev, int K, int C, int pooled,
+                               int sampling_ratio, int aligned, float *out_dev, void *stream);
+int dib_roi_align_nhwc_backward(const float *grad_out_dev, const int *H, const int *W, const float *scale,
+                                int n_levels, const float *rois_dev, const int *level_dev, int K, int C, int pooled,
+                                int sampling_ratio, int aligned, float *const *grad_feat_dev, void *stream);
 size_t dib_nms_workspace_bytes(int n);
 int dib_nms(const float *boxes_sorted_dev, int n, float iou_threshold, void *workspace_dev,
             long long *keep_dev, int *count_dev, void *stream);

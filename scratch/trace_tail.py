@@ -1,0 +1,18 @@
+"""Aggregate the last `--ms` milliseconds of a rocprofv3 kernel_trace.csv by kernel name."""
+import csv, sys, collections
+path, win_ms = sys.argv[1], float(sys.argv[2])
+rows = []
+with open(path) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+end = rows[-1][1]
+lo = end - int(win_ms * 1e6)
+agg = collections.defaultdict(lambda: [0, 0])
+busy = 0
+for s, e, n in rows:
+    if s >= lo:
+        agg[n][0] += 1; agg[n][1] += e - s; busy += e - s
+print("window %.1f ms, kernel-busy %.1f ms, %d launches" % (win_ms, busy / 1e6, sum(v[0] for v in agg.values())))
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    print("%6.2f%% %6d calls %9.1f us avg %9.2f ms  %s" % (100.0 * t / busy, c, t / c / 1e3, t / 1e6, n[:120]))

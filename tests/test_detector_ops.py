@@ -1,5 +1,7 @@
 """Detector ops: the plain-PyTorch fp32 restatements against brute-force definitions (CPU), and the
 HIP kernels against the plain-PyTorch fp32 reference (GPU).  Tolerances are stated per test."""
+from collections import OrderedDict
+
 import numpy as np
 import pytest
 import torch
@@ -105,7 +107,59 @@ def test_roi_align_hip_forward_backward(shape, scale):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 700, 3000])
+@pytest.mark.parametrize("shape,scale", [((2, 16, 50, 68), 0.25), ((1, 256, 25, 34), 0.125), ((2, 320, 13, 17), 1 / 16)])
+def test_roi_align_channels_last_matches_planar(shape, scale):
+    """NHWC kernels against the planar (NCHW) HIP kernels: forward bit-identical (same arithmetic
+    order per element), backward <= 2e-4 abs (atomics), and against the fp32 torch reference."""
+    rs = np.random.RandomState(11)
+    N, C, H, W = shape
+    feat = torch.tensor(rs.randn(*shape), dtype=torch.float32).cuda()
+    rois = _rois(rs, 53, N, H, W, scale).cuda()
+    f_a = feat.clone().requires_grad_(True)
+    f_b = feat.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out_a = ops.roi_align(f_a, rois, scale, 7, 2)
+    out_b = ops.roi_align(f_b, rois, scale, 7, 2)
+    assert out_b.is_contiguous() and torch.equal(out_a, out_b)
+    gout = torch.tensor(rs.randn(*out_a.shape), dtype=torch.float32).cuda()
+    out_a.backward(gout)
+    out_b.backward(gout)
+    assert f_b.grad.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(f_a.grad, f_b.grad, atol=2e-4)
+    f_ref = feat.cpu().requires_grad_(True)
+    ref = ops.roi_align_torch(f_ref, rois.cpu(), scale, 7, 2)
+    ref.backward(gout.cpu())
+    assert torch.allclose(out_b.cpu(), ref.detach(), atol=5e-5)
+    assert torch.allclose(f_b.grad.cpu(), f_ref.grad, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_multiscale_roi_align_one_launch_matches_per_level():
+    """MultiScaleRoIAlign on a channels-last pyramid (one launch, device-side level map) against the
+    per-level planar path, forward and backward."""
+    rs = np.random.RandomState(5)
+    sizes = [(64, 96), (32, 48), (16, 24), (8, 12)]
+    feats = OrderedDict((str(i), torch.tensor(rs.randn(2, 32, h, w), dtype=torch.float32).cuda()) for i, (h, w) in enumerate(sizes))
+    boxes = []
+    for _ in range(2):
+        c = rs.uniform(0, 1, (40, 2)) * [384, 256]
+        wh = np.exp(rs.uniform(np.log(8), np.log(380), (40, 2)))
+        b = np.concatenate([c - wh / 2, c + wh / 2], 1)
+        boxes.append(torch.tensor(np.clip(b, 0, [383, 255, 383, 255]), dtype=torch.float32).cuda())
+    pool = ops.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    res = {}
+    for name, fmt in (("planar", torch.contiguous_format), ("nhwc", torch.channels_last)):
+        fs = OrderedDict((k, v.clone().contiguous(memory_format=fmt).requires_grad_(True)) for k, v in feats.items())
+        out = pool(fs, boxes, [(256, 384), (256, 384)])
+        out.square().sum().backward()
+        res[name] = (out.detach(), [v.grad for v in fs.values()])
+    assert torch.equal(res["planar"][0], res["nhwc"][0])
+    for a, b in zip(res["planar"][1], res["nhwc"][1]):
+        a = torch.zeros_like(b) if a is None else a      # the per-level path leaves unused levels without a gradient
+        assert torch.allclose(a, b, atol=5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 700, 1025, 3000, 4097, 9000])
 def test_nms_hip_matches_torch(n):
     rs = np.random.RandomState(n)
     c = rs.uniform(0, 400, (n, 2)); s = rs.uniform(5, 80, (n, 2))
