@@ -58,6 +58,8 @@ _SIGNATURES = {
     "dib_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "dib_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_nms_batched": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     # test hook, not part of the drop-in boundary
     "dib_sparse_blur_generic": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,

@@ -352,14 +352,33 @@ template <int NW, int TPW>
 __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K,
                                                                      unsigned long long *dbg) {
   extern __shared__ uint2 lds[];
-  const int tile = blockIdx.x;
-  // image lookup: tile_begin[] is contiguous in the kernel arguments (a handful of scalar loads)
-  int i = 0;
+  // Tile order.  Workgroups with equal blockIdx % 8 share an XCD (and its 4 MB L2); hardware hands
+  // consecutive ids to different XCDs, so with a flat tile order no two neighbouring tiles ever
+  // share an L2 and every halo row comes from HBM again.  Instead each XCD group x walks, image after
+  // image, the x-th eighth of that image's tiles: neighbouring tiles run on one XCD close in time
+  // (halo rows hit in L2), and every XCD still gets an equal share of every image, so PSFs of
+  // different tap counts do not unbalance the XCDs.  (A performance choice only: any tile order
+  // gives the same output.)
+  int i = -1, local = 0;
+  if (batch.xcd_bands) {
+    const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
+    int cum = 0;
+    for (int k = 0; k < batch.n; ++k) {
+      const int T = batch.tile_begin[k + 1] - batch.tile_begin[k];
+      const int lo = (x * T) >> 3, hi = ((x + 1) * T) >> 3;
+      if (i < 0 && l < cum + (hi - lo)) { i = k; local = lo + (l - cum); }
+      cum += hi - lo;
+    }
+    if (i < 0) return;  // the grid is 8 x the longest per-XCD list
+  } else {
+    const int tile = blockIdx.x;
+    i = 0;
 #pragma unroll
-  for (int k = 1; k < MAX_BATCH; ++k)
-    if (k < batch.n && tile >= batch.tile_begin[k]) i = k;
+    for (int k = 1; k < MAX_BATCH; ++k)
+      if (k < batch.n && tile >= batch.tile_begin[k]) i = k;
+    local = tile - batch.tile_begin[i];
+  }
   const ImageDesc &d = batch.img[i];
-  int local = tile - d.tile_begin;
   const int per_ch = d.tiles_x * d.tiles_y;   // tiles_y counts STACKS of TPW vertically adjacent tiles
   const int ch = local / per_ch;
   local -= ch * per_ch;
@@ -428,7 +447,8 @@ using namespace dib;
 static unsigned long long *g_stamp_buffer = nullptr;
 extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) { g_stamp_buffer = (unsigned long long *)dev_ptr; }
 // Tuning knobs (all variants are bit-identical): waves per workgroup (4 or 8), tiles per workgroup (1 or 2)
-static int g_nw = 4, g_tpw = 1;
+static int g_nw = 4, g_tpw = 1, g_xcd_bands = 1;
+extern "C" void dib_debug_set_tile_order(int xcd_bands) { g_xcd_bands = xcd_bands ? 1 : 0; }
 extern "C" void dib_debug_set_variant(int nw, int tpw) { g_nw = (nw == 4) ? 4 : 8; g_tpw = (tpw == 2) ? 2 : 1; }
 
 
@@ -490,12 +510,27 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     if (tiled.n == 0) break;
     tiled.total_tiles = tiles;
     generic.total_tiles = gblocks;
+    tiled.xcd_bands = g_xcd_bands;
+    generic.xcd_bands = 0;
+    int grid = tiles;
+    if (g_xcd_bands) {   // 8 x the longest per-XCD tile list (lists differ by at most one tile per image)
+      int longest = 0;
+      for (int x = 0; x < 8; ++x) {
+        int len = 0;
+        for (int k = 0; k < tiled.n; ++k) {
+          const int T = (k + 1 < tiled.n ? tiled.tile_begin[k + 1] : tiles) - tiled.tile_begin[k];
+          len += (((x + 1) * T) >> 3) - ((x * T) >> 3);
+        }
+        longest = len > longest ? len : longest;
+      }
+      grid = 8 * longest;
+    }
     if (dtype == DIB_F16) {
       for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
-      if (g_nw == 4 && g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1>), dim3(tiles), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
-      else if (g_nw == 4) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 2>), dim3(tiles), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
-      else if (g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 1>), dim3(tiles), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
-      else hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 2>), dim3(tiles), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      if (g_nw == 4 && g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else if (g_nw == 4) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 2>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else if (g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 1>), dim3(grid), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 2>), dim3(grid), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
     } else {
       hipLaunchKernelGGL((blur_generic_kernel<float, false>), dim3(gblocks), dim3(256), 0, s, generic, (const int *)tables_dev, K);
     }
@@ -516,6 +551,7 @@ extern "C" int dib_sparse_blur_generic(const void *in_dev, void *out_dev, int C,
   g.img[0] = d;
   int blocks = (int)(((long long)C * H * W + 255) / 256);
   g.total_tiles = blocks;
+  g.xcd_bands = 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DIB_F16)
     hipLaunchKernelGGL((blur_generic_kernel<__half, false>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);

@@ -84,6 +84,7 @@ struct BlurBatch {
   int tile_begin[MAX_BATCH + 1];  // copy of img[i].tile_begin (+ total), contiguous for the image lookup
   int n;
   int total_tiles;
+  int xcd_bands;  // tile order of the tiled kernel: 1 = per-XCD bands of every image, 0 = flat
 };
 
 }  // namespace dib

@@ -214,6 +214,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__
   const int rb = blockIdx.y, cb = blockIdx.x, lane = threadIdx.x;
   if (cb < rb) return;  // only j > i matters
   const int nblk = (n + 63) / 64;
+  boxes += (size_t)blockIdx.z * n;               // one box set per blockIdx.z
+  mask += (size_t)blockIdx.z * n * nblk;
   __shared__ float4 cols[64];
   const int cj = cb * 64 + lane;
   if (cj < n) cols[lane] = boxes[cj];
@@ -237,12 +239,22 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4 *__restrict__
 // WPR = words per row handled (power of two >= nblk), RG = 1024 / WPR row groups, RPT rows per thread.
 template <int WPR>
 __global__ __launch_bounds__(1024) void nms_reduce_kernel(const unsigned long long *__restrict__ mask, int n,
+                                                          const unsigned char *__restrict__ valid,
                                                           long long *__restrict__ keep, int *__restrict__ count) {
   constexpr int RG = 1024 / WPR, RPT = 64 / RG;
   const int nblk = (n + 63) / 64, t = threadIdx.x, lane = t & 63;
   const int w = t % WPR, rg = t / WPR;
+  mask += (size_t)blockIdx.x * n * nblk;          // one box set per workgroup
+  keep += (size_t)blockIdx.x * n;
+  count += blockIdx.x;
   __shared__ unsigned long long removed[256];
   if (t < 256) removed[t] = 0;
+  if (valid) {  // boxes flagged invalid start out removed: never kept, never suppressing
+    __syncthreads();
+    valid += (size_t)blockIdx.x * n;
+    for (int i = t; i < n; i += 1024)
+      if (!valid[i]) atomicOr(&removed[i >> 6], 1ull << (i & 63));
+  }
   unsigned long long cur[RPT], nxt[RPT], dcur, dnxt;
   auto fetch = [&](int blk, unsigned long long (&buf)[RPT], unsigned long long &diag) {
     const int row0 = blk * 64;
@@ -285,6 +297,7 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const unsigned long lo
     __syncthreads();
   }
   if (t == 0) *count = kept;
+  for (int i = kept + t; i < n; i += 1024) keep[i] = 0;  // defined tail: callers may gather through the padded list
 }
 
 }  // namespace dib
@@ -370,22 +383,29 @@ extern "C" size_t dib_nms_workspace_bytes(int n) {
   return (size_t)n * nblk * sizeof(unsigned long long);
 }
 
-extern "C" int dib_nms(const float *boxes_sorted_dev, int n, float iou_threshold, void *workspace_dev, long long *keep_dev,
-                       int *count_dev, void *stream) {
-  if (n < 0 || n > 16384) { set_error("dib_nms: n must be in [0, 16384], got %d", n); return DIB_EINVAL; }
+extern "C" int dib_nms_batched(const float *boxes_sorted_dev, const unsigned char *valid_dev, int B, int n,
+                               float iou_threshold, void *workspace_dev, long long *keep_dev, int *count_dev, void *stream) {
+  if (n < 0 || n > 16384 || B < 0) { set_error("dib_nms: n must be in [0, 16384] and B >= 0, got n=%d B=%d", n, B); return DIB_EINVAL; }
+  if (B == 0) return DIB_OK;
   if (!count_dev) { set_error("dib_nms: null count pointer"); return DIB_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
-  if (n == 0) { DIB_HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(int), s)); return DIB_OK; }
+  if (n == 0) { DIB_HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(int) * (size_t)B, s)); return DIB_OK; }
   if (!boxes_sorted_dev || !workspace_dev || !keep_dev) { set_error("dib_nms: null pointer"); return DIB_EINVAL; }
   if (((uintptr_t)boxes_sorted_dev & 15) != 0) { set_error("dib_nms: boxes must be 16-byte aligned"); return DIB_EINVAL; }
+  if (B > 65535) { set_error("dib_nms: at most 65535 box sets per call"); return DIB_EINVAL; }
   const int nblk = (n + 63) / 64;
   // no memset: pass 2 reads only the diagonal and upper blocks of rows < n, all written by pass 1
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, s, (const float4 *)boxes_sorted_dev, n, iou_threshold,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk, B), dim3(64), 0, s, (const float4 *)boxes_sorted_dev, n, iou_threshold,
                      (unsigned long long *)workspace_dev);
   const unsigned long long *m = (const unsigned long long *)workspace_dev;
-  if (nblk <= 16) hipLaunchKernelGGL(nms_reduce_kernel<16>, dim3(1), dim3(1024), 0, s, m, n, keep_dev, count_dev);
-  else if (nblk <= 64) hipLaunchKernelGGL(nms_reduce_kernel<64>, dim3(1), dim3(1024), 0, s, m, n, keep_dev, count_dev);
-  else hipLaunchKernelGGL(nms_reduce_kernel<256>, dim3(1), dim3(1024), 0, s, m, n, keep_dev, count_dev);
+  if (nblk <= 16) hipLaunchKernelGGL(nms_reduce_kernel<16>, dim3(B), dim3(1024), 0, s, m, n, valid_dev, keep_dev, count_dev);
+  else if (nblk <= 64) hipLaunchKernelGGL(nms_reduce_kernel<64>, dim3(B), dim3(1024), 0, s, m, n, valid_dev, keep_dev, count_dev);
+  else hipLaunchKernelGGL(nms_reduce_kernel<256>, dim3(B), dim3(1024), 0, s, m, n, valid_dev, keep_dev, count_dev);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
+}
+
+extern "C" int dib_nms(const float *boxes_sorted_dev, int n, float iou_threshold, void *workspace_dev, long long *keep_dev,
+                       int *count_dev, void *stream) {
+  return dib_nms_batched(boxes_sorted_dev, nullptr, 1, n, iou_threshold, workspace_dev, keep_dev, count_dev, stream);
 }

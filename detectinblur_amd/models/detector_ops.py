@@ -161,6 +161,35 @@ def nms(boxes, scores, iou_threshold):
     return order[keep[:int(count.item())]]
 
 
+def nms_sets_sorted(boxes, valid, iou_threshold):
+    """Greedy NMS on B independent box sets at once.  boxes [B, n, 4], every set already sorted by
+    descending score; valid [B, n] bool (False = the box takes no part) or None.
+    Returns (keep [B, n] int64, count [B] int32): keep[b, :count[b]] are the surviving positions in
+    score order, the rest of the row is 0.  No host synchronisation on the GPU path."""
+    B, n = boxes.shape[0], boxes.shape[1]
+    keep = torch.zeros((B, n), dtype=torch.int64, device=boxes.device)
+    count = torch.zeros((B,), dtype=torch.int32, device=boxes.device)
+    if B == 0 or n == 0:
+        return keep, count
+    if not boxes.is_cuda:
+        fake = torch.arange(n, 0, -1, dtype=torch.float32)
+        for b in range(B):
+            idx = torch.arange(n) if valid is None else torch.where(valid[b])[0]
+            k = idx[_nms_torch(boxes[b, idx].float(), fake[idx], iou_threshold)]
+            keep[b, :k.numel()] = k
+            count[b] = k.numel()
+        return keep, count
+    if n > 16384:
+        raise ValueError("nms_sets_sorted: at most 16384 boxes per set")
+    l = _lib.lib()
+    b = boxes.float().contiguous()
+    v = None if valid is None else valid.to(torch.uint8).contiguous()
+    ws = torch.empty(B * l.dib_nms_workspace_bytes(n), dtype=torch.uint8, device=b.device)
+    _lib.check(l.dib_nms_batched(b.data_ptr(), v.data_ptr() if v is not None else None, B, n, float(iou_threshold),
+                                 ws.data_ptr(), keep.data_ptr(), count.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return keep, count
+
+
 def batched_nms(boxes, scores, groups, iou_threshold):
     """NMS within each group (FPN level / class): boxes of different groups are moved apart."""
     if boxes.numel() == 0:

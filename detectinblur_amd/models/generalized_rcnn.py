@@ -30,7 +30,19 @@ class GeneralizedRCNN(nn.Module):
                     raise ValueError("Expected target boxes to be a tensor of shape [N, 4], got {:}.".format(boxes.shape))
         original_sizes = [(int(img.shape[-2]), int(img.shape[-1])) for img in images]
         images, targets = self.transform(images, targets, newMeans, newSTDs)
+        # degenerate-box check (reference generalized_rcnn.py:119-129): the flags are computed here, on
+        # the device, but READ only after the backbone and the RPN have been enqueued -- reading them first would
+        # stall the host behind the previous step's backward and leave the GPU idle while the
+        # forward pass is issued.  Same ValueError, raised before anything is returned.
+        degenerate = None
         if targets is not None:
+            flags = [(t["boxes"][:, 2:] <= t["boxes"][:, :2]).any() for t in targets]
+            degenerate = torch.stack(flags) if flags else None
+        features = self.backbone(images.tensors)
+        if isinstance(features, torch.Tensor):
+            features = OrderedDict([("0", features)])
+        proposals, proposal_losses = self.rpn(images, features, targets)
+        if degenerate is not None and bool(degenerate.any()):
             for idx, target in enumerate(targets):
                 boxes = target["boxes"]
                 bad = boxes[:, 2:] <= boxes[:, :2]
@@ -38,10 +50,6 @@ class GeneralizedRCNN(nn.Module):
                     bb = boxes[bad.any(dim=1).nonzero().view(-1)[0]].tolist()
                     raise ValueError("All bounding boxes should have positive height and width."
                                      " Found invaid box {} for target at index {}.".format(bb, idx))
-        features = self.backbone(images.tensors)
-        if isinstance(features, torch.Tensor):
-            features = OrderedDict([("0", features)])
-        proposals, proposal_losses = self.rpn(images, features, targets)
         detections, detector_losses = self.roi_heads(features, proposals, images.image_sizes, targets)
         detections = self.transform.postprocess(detections, images.image_sizes, original_sizes)
         if self.training:

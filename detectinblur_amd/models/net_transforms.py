@@ -5,6 +5,7 @@ the `crop_images` mode the blur-estimator input uses (:226-236), and box rescali
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -22,8 +23,9 @@ class ImageList(object):
 
 
 def resize_boxes(boxes, original_size, new_size):
-    rh, rw = (torch.tensor(n, dtype=torch.float32, device=boxes.device) / torch.tensor(o, dtype=torch.float32, device=boxes.device)
-              for n, o in zip(new_size, original_size))
+    # float32 ratios computed on the host: a 0-dim device tensor per ratio would cost one blocking
+    # H2D copy each (4 per image); a Python float holding the float32 quotient multiplies identically
+    rh, rw = (float(np.float32(n) / np.float32(o)) for n, o in zip(new_size, original_size))
     x1, y1, x2, y2 = boxes.unbind(1)
     return torch.stack((x1 * rw, y1 * rh, x2 * rw, y2 * rh), dim=1)
 
@@ -38,9 +40,25 @@ class GeneralizedRCNNTransform(nn.Module):
         self.training = training
         self.normalize_images = normalize_images
 
+    _stat_cache = {}
+
+    @classmethod
+    def _stat(cls, values, dtype, device):
+        """Per-channel statistics as a device tensor.  The rows repeat from step to step (ImageNet
+        stats, or one of the 15 custom-norm rows), so each distinct row is uploaded once: a fresh
+        `as_tensor(..., device=)` per image is a blocking H2D copy that stalls the host behind all
+        queued GPU work, 16 times per batch."""
+        key = (tuple(float(v) for v in values), dtype, str(device))
+        t = cls._stat_cache.get(key)
+        if t is None:
+            if len(cls._stat_cache) > 256:
+                cls._stat_cache.clear()
+            t = cls._stat_cache[key] = torch.as_tensor(key[0], dtype=dtype, device=device)
+        return t
+
     def normalize(self, image, mean, std):
-        mean = torch.as_tensor(mean, dtype=image.dtype, device=image.device)
-        std = torch.as_tensor(std, dtype=image.dtype, device=image.device)
+        mean = self._stat(mean, image.dtype, image.device)
+        std = self._stat(std, image.dtype, image.device)
         return (image - mean[:, None, None]) / std[:, None, None]
 
     def resize(self, image, target):

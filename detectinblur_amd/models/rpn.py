@@ -29,6 +29,13 @@ class AnchorGenerator(nn.Module):
     def forward(self, image_list, feature_maps):
         img_h, img_w = image_list.tensors.shape[-2:]
         dtype, device = feature_maps[0].dtype, feature_maps[0].device
+        # anchors depend only on the shapes: build them once per (image, pyramid) geometry.  Building
+        # them every step costs ten blocking H2D copies (the size / ratio tuples) in the middle of the
+        # forward pass, i.e. a full host stall behind the backbone.
+        key = (int(img_h), int(img_w), tuple(tuple(f.shape[-2:]) for f in feature_maps), dtype, str(device))
+        cached = getattr(self, "_cache", None)
+        if cached is not None and cached[0] == key:
+            return [cached[1] for _ in image_list.image_sizes]
         per_level = []
         for f, s, a in zip(feature_maps, self.sizes, self.aspect_ratios):
             gh, gw = f.shape[-2:]
@@ -39,6 +46,7 @@ class AnchorGenerator(nn.Module):
             shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
             per_level.append((shifts[:, None, :] + self._base(s, a, dtype, device)[None]).reshape(-1, 4))
         anchors = torch.cat(per_level)
+        self._cache = (key, anchors)
         return [anchors for _ in image_list.image_sizes]
 
 
@@ -100,14 +108,31 @@ class RegionProposalNetwork(nn.Module):
         idx = torch.cat(idx, dim=1)
         rows = torch.arange(N, device=proposals.device)[:, None]
         objectness, levels, proposals = objectness[rows, idx], levels[None].expand(N, -1)[rows, idx], proposals[rows, idx]
-        boxes_out, scores_out = [], []
-        for boxes, scores, lvl, size in zip(proposals, objectness, levels, image_sizes):
-            boxes = ops.clip_boxes_to_image(boxes, size)
-            keep = ops.remove_small_boxes(boxes, self.min_size)
-            boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
-            keep = ops.batched_nms(boxes, scores, lvl, self.nms_thresh)[:self._n(self._post)]
-            boxes_out.append(boxes[keep])
-            scores_out.append(scores[keep])
+        # From here on every image goes through the same tensor ops at once, and nothing is compacted
+        # before the NMS: boxes that torchvision would drop as too small are flagged invalid instead
+        # (they are never kept and never suppress).  One host sync per batch (the kept counts) instead
+        # of two per image, ~15 launches instead of ~20 per image.
+        sizes = torch.tensor([[float(s[1]), float(s[0])] for s in image_sizes], dtype=proposals.dtype)   # (w, h) per image
+        if proposals.is_cuda:
+            sizes = sizes.pin_memory().to(proposals.device, non_blocking=True)
+        x = proposals[..., 0::2].clamp(min=0).minimum(sizes[:, None, 0:1])
+        y = proposals[..., 1::2].clamp(min=0).minimum(sizes[:, None, 1:2])
+        boxes = torch.stack((x[..., 0], y[..., 0], x[..., 1], y[..., 1]), dim=-1)                        # clip_boxes_to_image
+        valid = ((boxes[..., 2] - boxes[..., 0]) >= self.min_size) & ((boxes[..., 3] - boxes[..., 1]) >= self.min_size)
+        scores, order = objectness.sort(dim=1, descending=True)
+        boxes = boxes.gather(1, order[..., None].expand(-1, -1, 4))
+        levels, valid = levels.gather(1, order), valid.gather(1, order)
+        # batched_nms: boxes of different levels are moved apart by (largest coordinate + 1) per level
+        top = torch.where(valid[..., None], boxes, boxes.new_zeros(())).amax(dim=(1, 2))
+        shifted = boxes + (levels.to(boxes) * (top[:, None] + 1))[..., None]
+        keep, count = ops.nms_sets_sorted(shifted, valid, self.nms_thresh)
+        post = self._n(self._post)
+        keep = keep[:, :post]
+        boxes = boxes.gather(1, keep[..., None].expand(-1, -1, 4))
+        scores = scores.gather(1, keep)
+        counts_host = count.clamp(max=post).tolist()        # the one synchronisation point
+        boxes_out = [boxes[i, :c] for i, c in enumerate(counts_host)]
+        scores_out = [scores[i, :c] for i, c in enumerate(counts_host)]
         return boxes_out, scores_out
 
     def assign_targets(self, anchors, targets):

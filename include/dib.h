@@ -122,7 +122,8 @@ int dib_psf_rasterize(const double *traj_dev, int B, int iters, const double *fr
  *   rois_dev: [K][5] = (batch index, x1, y1, x2, y2) in image coordinates.
  *   dib_roi_align_backward ACCUMULATES into grad_feat_dev (caller zero-fills it first).
  *   dib_nms: boxes [n][4] xyxy already sorted by descending score; keep_dev receives the kept
- *   indices (ascending = score order), count_dev their number; workspace of dib_nms_workspace_bytes(n).
+ *   indices (ascending = score order; entries past the count are 0), count_dev their number;
+ *   workspace of dib_nms_workspace_bytes(n).
  * ------------------------------------------------------------------------------------- */
 int dib_roi_align_forward(const float *feat_dev, const float *rois_dev, int K, int C, int H, int W,
                           float spatial_scale, int pooled, int sampling_ratio, int aligned,
@@ -144,6 +145,13 @@ int dib_roi_align_nhwc_backward(const float *grad_out_dev, const int *H, const i
 size_t dib_nms_workspace_bytes(int n);
 int dib_nms(const float *boxes_sorted_dev, int n, float iou_threshold, void *workspace_dev,
             long long *keep_dev, int *count_dev, void *stream);
+/* B independent box sets of n boxes each in one launch pair (RPN: one set per image).  boxes [B][n][4],
+ * keep [B][n] (entries past count[b] are 0), count [B]; valid_dev (may be NULL): [B][n] bytes, 0 = the
+ * box takes no part (neither kept nor suppressing), which replaces a compaction + host sync in front
+ * of the call; workspace: B * dib_nms_workspace_bytes(n). */
+int dib_nms_batched(const float *boxes_sorted_dev, const unsigned char *valid_dev, int B, int n,
+                    float iou_threshold, void *workspace_dev, long long *keep_dev, int *count_dev,
+                    void *stream);
 
 #ifdef __cplusplus
 }

@@ -18,12 +18,15 @@ for nw in (8,):
     for _ in range(30):
         e0.record(); blur_ops.sparse_blur(list(images), idx, tables); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1))
     ts.sort(); print("NW=%d  kernel ms median %.4f min %.4f" % (nw, ts[len(ts)//2], ts[0]))
-    nblk = 1024
+    nblk = 4096
     dbg = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
     l.dib_debug_set_stamp_buffer(dbg.data_ptr())
     blur_ops.sparse_blur(list(images), idx, tables); torch.cuda.synchronize()
     l.dib_debug_set_stamp_buffer(None)
     d = dbg.cpu().numpy().reshape(nblk, 8).astype(np.int64)
+    d = d[d[:, 4] != 0]
+    nblk = len(d); print("   workgroups stamped:", nblk)
+    print("   segments per PSF:", [len(tables.segments(i)) for i in range(8)], "taps:", [tables.header(i)[0] for i in range(8)])
     for name, a in (("fill", d[:,1]-d[:,0]), ("accumulate", d[:,2]-d[:,1]), ("rest+store", d[:,3]-d[:,2]), ("total", d[:,3]-d[:,0])):
         print("   %-12s mean %8.0f p10 %8.0f p50 %8.0f p90 %8.0f" % (name, a.mean(), np.percentile(a,10), np.percentile(a,50), np.percentile(a,90)))
     ws, we = d[:,4], d[:,5]

@@ -16,3 +16,22 @@ for s, e, n in rows:
 print("window %.1f ms, kernel-busy %.1f ms, %d launches" % (win_ms, busy / 1e6, sum(v[0] for v in agg.values())))
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     print("%6.2f%% %6d calls %9.1f us avg %9.2f ms  %s" % (100.0 * t / busy, c, t / c / 1e3, t / 1e6, n[:120]))
+
+# ---- idle gaps: where the GPU waits for the host ---------------------------------------------------
+win = [(s, e, n) for s, e, n in rows if s >= lo]
+gaps = collections.defaultdict(lambda: [0, 0])
+idle = 0
+cur_end = win[0][1]
+prev = win[0][2]
+for s, e, n in win[1:]:
+    if s > cur_end:
+        g = s - cur_end
+        idle += g
+        if g > 20000:
+            key = (prev[:60], n[:60])
+            gaps[key][0] += 1; gaps[key][1] += g
+    if e > cur_end:
+        cur_end = e; prev = n
+print("\nidle %.1f ms in window; gaps > 20 us by (kernel before -> kernel after):" % (idle / 1e6))
+for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:30]:
+    print("%8.2f ms %5d x  %s  ->  %s" % (t / 1e6, c, a, b))

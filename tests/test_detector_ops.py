@@ -170,3 +170,29 @@ def test_nms_hip_matches_torch(n):
     assert got.cpu().tolist() == want.tolist()
     groups = torch.tensor(rs.randint(0, 3, n))
     assert ops.batched_nms(boxes.cuda(), scores.cuda(), groups.cuda(), 0.5).cpu().tolist() == ops.batched_nms(boxes, scores, groups, 0.5).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [200, 5000])
+def test_nms_sets_sorted_matches_per_set_nms(n):
+    """B box sets in one launch pair, with a validity mask, against NMS run set by set on the
+    compacted (valid-only) boxes -- the semantics RPN.filter_proposals relies on."""
+    rs = np.random.RandomState(n)
+    B = 3
+    c = rs.uniform(0, 600, (B, n, 2)); s = rs.uniform(5, 120, (B, n, 2))
+    boxes = torch.tensor(np.concatenate([c - s / 2, c + s / 2], 2), dtype=torch.float32)
+    valid = torch.tensor(rs.random_sample((B, n)) > 0.2)
+    valid[1] = True
+    keep, count = ops.nms_sets_sorted(boxes.cuda(), valid.cuda(), 0.7)
+    keep_c, count_c = ops.nms_sets_sorted(boxes, valid, 0.7)            # CPU restatement
+    fake = torch.arange(n, 0, -1, dtype=torch.float32)
+    for b in range(B):
+        idx = torch.where(valid[b])[0]
+        want = idx[ops.nms(boxes[b, idx].cuda(), fake[idx].cuda(), 0.7).cpu()]
+        k = int(count[b])
+        assert keep[b, :k].cpu().tolist() == want.tolist()
+        assert int(keep[b, k:].abs().sum()) == 0
+        assert keep_c[b, :int(count_c[b])].tolist() == want.tolist()
+    k2, c2 = ops.nms_sets_sorted(boxes.cuda(), None, 0.7)
+    for b in range(B):
+        assert k2[b, :int(c2[b])].cpu().tolist() == ops.nms(boxes[b].cuda(), fake.cuda(), 0.7).cpu().tolist()
