@@ -195,6 +195,33 @@ __device__ __forceinline__ void tap_loop_r4(h2 (&acc)[4][2], unsigned long long 
 #undef DIB_READ4
 #undef DIB_NEXTTAP
 
+// DIB_ACC_FP32: acc32 = acc32 + float(P) * float(w), taps in the same order, ONE rounding to fp16 at the
+// store.  The product of two fp16 values is exact in fp32 (11 + 11 <= 24 significand bits), so fused
+// and unfused forms agree and the result is reproducible bit for bit on any IEEE fp32 machine (the
+// oracle restates it with numpy float32).  Plain C++: this mode trades the hand-scheduled loop for
+// accuracy (error vs exact arithmetic ~2^-12 relative instead of ~ntaps * 2^-12).
+template <int R>
+__device__ __forceinline__ void tap_loop_fp32(float (&acc)[R][4], const unsigned *__restrict__ ltaps, int t0, int n,
+                                              unsigned lane_addr) {
+#pragma clang fp contract(off)
+  for (int t = t0; t < t0 + n; ++t) {
+    const unsigned lt = __builtin_amdgcn_readfirstlane(ltaps[t]);
+    const float w = (float)__builtin_bit_cast(_Float16, (unsigned short)(lt >> 16));
+    const unsigned a = lane_addr + (lt & 0xffffu);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      typedef unsigned uvec2 __attribute__((ext_vector_type(2)));
+      const uvec2 q = *(const __attribute__((address_space(3))) uvec2 *)(size_t)(a + (unsigned)(i * PQ * 8));
+      const float p0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.x & 0xffffu));
+      const float p1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.x >> 16));
+      const float p2 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.y & 0xffffu));
+      const float p3 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.y >> 16));
+      acc[i][0] = acc[i][0] + p0 * w; acc[i][1] = acc[i][1] + p1 * w;
+      acc[i][2] = acc[i][2] + p2 * w; acc[i][3] = acc[i][3] + p3 * w;
+    }
+  }
+}
+
 // Diagnostic stamps (nullptr in every product launch): shader-clock readings of lane 0 of wave 0.
 __device__ __forceinline__ void stamp(unsigned long long *dbg, int slot) {
   if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
@@ -210,7 +237,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *img_bas
 }
 
 // One workgroup = one (image, channel, 256 x 32 tile).  NW waves, R = 32 / NW rows per lane.
-template <int NW, bool ZERO>
+template <int NW, bool ZERO, bool ACC32>
 __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx,
                                               int ty, uint2 *lds, unsigned long long *dbg) {
 #pragma clang fp contract(off)
@@ -231,8 +258,12 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
   const int w2 = W * 2;
 
   h2 acc[R][2];
+  float acc32[R][4];
 #pragma unroll
-  for (int i = 0; i < R; ++i) { acc[i][0] = h2{0, 0}; acc[i][1] = h2{0, 0}; }
+  for (int i = 0; i < R; ++i) {
+    acc[i][0] = h2{0, 0}; acc[i][1] = h2{0, 0};
+    acc32[i][0] = acc32[i][1] = acc32[i][2] = acc32[i][3] = 0.f;
+  }
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
   const unsigned lane_addr = lds0 + (unsigned)((wave * R) * PQ + lane) * 8u;
@@ -304,7 +335,8 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
     if (sg == 0) stamp(dbg, 1);
 
     // ---- accumulate: taps of the segment in row-major order (hand-written loop above) -----------------
-    if constexpr (R == 8) tap_loop_r8(acc, ltaps, t0, n, lane_addr);
+    if constexpr (ACC32) tap_loop_fp32<R>(acc32, reinterpret_cast<const unsigned *>(ltaps), t0, n, lane_addr);
+    else if constexpr (R == 8) tap_loop_r8(acc, ltaps, t0, n, lane_addr);
     else tap_loop_r4(acc, ltaps, t0, n, lane_addr);
     if (sg == 0) stamp(dbg, 2);
   }
@@ -321,7 +353,13 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
         const int soff = y * w2;
         // halves are extracted with integer ops: hipcc (ROCm 7.2) stored the LOW half twice when the
         // high element of the fp16x2 accumulator was taken with a vector subscript
-        const unsigned a = __builtin_bit_cast(unsigned, acc[i][0]), b = __builtin_bit_cast(unsigned, acc[i][1]);
+        unsigned a = __builtin_bit_cast(unsigned, acc[i][0]), b = __builtin_bit_cast(unsigned, acc[i][1]);
+        if constexpr (ACC32) {
+          a = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][0]) |
+              ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][1]) << 16);
+          b = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][2]) |
+              ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][3]) << 16);
+        }
         if (xr > 0) __builtin_amdgcn_raw_buffer_store_b16((short)(a & 0xffffu), out_rsrc, voff, soff, 0);
         if (xr > 64) __builtin_amdgcn_raw_buffer_store_b16((short)(a >> 16), out_rsrc, voff + 128u, soff, 0);
         if (xr > 128) __builtin_amdgcn_raw_buffer_store_b16((short)(b & 0xffffu), out_rsrc, voff + 256u, soff, 0);
@@ -348,7 +386,7 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
 // queue was 30-60 % slower -- the returning atomics and the per-tile descriptor fetches sit on the
 // critical path of every tile, and static striding loses ~20 us to tap-count imbalance; 8-wave
 // workgroups double the wave launches, whose rate bounds this kernel at ~32 us for 28,800 waves.)
-template <int NW, int TPW>
+template <int NW, int TPW, bool ACC32 = false>
 __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K,
                                                                      unsigned long long *dbg) {
   extern __shared__ uint2 lds[];
@@ -389,8 +427,8 @@ __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch b
     const int ty = sy * TPW + rep;
     if (ty * TH >= d.H) break;
     if (rep > 0) __syncthreads();  // the previous tile's window reads are over
-    if (zero) blur_tile_f16<NW, true>(d, tab, K, ch, tx, ty, lds, dbg);
-    else blur_tile_f16<NW, false>(d, tab, K, ch, tx, ty, lds, dbg);
+    if (zero) blur_tile_f16<NW, true, ACC32>(d, tab, K, ch, tx, ty, lds, dbg);
+    else blur_tile_f16<NW, false, ACC32>(d, tab, K, ch, tx, ty, lds, dbg);
   }
 }
 
@@ -409,7 +447,7 @@ template <> struct Arith<float> {
   static __device__ V weight(unsigned bits) { return __uint_as_float(bits); }
 };
 
-template <typename T, bool ONLY_WIDE>
+template <typename T, bool ACC32>
 __global__ __launch_bounds__(256) void blur_generic_kernel(BlurBatch batch, const int *__restrict__ tables, int K) {
 #pragma clang fp contract(off)
   using V = typename Arith<T>::V;
@@ -426,6 +464,7 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(BlurBatch batch, cons
   const int ntaps = tab[HDR_NTAPS];
   const uint2 *taps = reinterpret_cast<const uint2 *>(tab + table_taps_off(K));
   V acc = 0;
+  float acc32 = 0.f;  // DIB_ACC_FP32 (fp16 images): exact products, fp32 running sum, one final rounding
   for (int t = 0; t < ntaps; ++t) {
     const uint2 tap = taps[t];
     const int r = tap.x >> 8, c = tap.x & 255;
@@ -433,10 +472,14 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(BlurBatch batch, cons
     const int sy = map_coord(y + pb - r, H, pa, pb, mode, zr);
     const int sx = map_coord(x + pb - c, W, pa, pb, mode, zc);
     V p = (zr || zc) ? V(0) : src[(size_t)sy * W + sx];
-    V prod = p * Arith<T>::weight(tap.y);
-    acc = acc + prod;
+    if constexpr (ACC32) {
+      acc32 = acc32 + (float)p * (float)Arith<T>::weight(tap.y);
+    } else {
+      V prod = p * Arith<T>::weight(tap.y);
+      acc = acc + prod;
+    }
   }
-  reinterpret_cast<V *>(d.out)[e] = acc;
+  reinterpret_cast<V *>(d.out)[e] = ACC32 ? (V)acc32 : acc;
 }
 
 }  // namespace dib
@@ -461,7 +504,8 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   }
   if (K != 128 && K != 256) { set_error("dib_sparse_blur: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
   if (dtype != DIB_F16 && dtype != DIB_F32) { set_error("dib_sparse_blur: unknown dtype %d", dtype); return DIB_EINVAL; }
-  if (acc_mode != DIB_ACC_BITEXACT) { set_error("dib_sparse_blur: accumulation mode %d not available", acc_mode); return DIB_EINVAL; }
+  if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FP32) { set_error("dib_sparse_blur: unknown accumulation mode %d", acc_mode); return DIB_EINVAL; }
+  if (acc_mode == DIB_ACC_FP32 && dtype != DIB_F16) { set_error("dib_sparse_blur: DIB_ACC_FP32 applies to fp16 images only (fp32 images already accumulate in fp32)"); return DIB_EINVAL; }
   for (int i = 0; i < B; ++i) {
     if (table_index[i] < 0) continue;
     if (!in_dev[i] || !out_dev[i] || C[i] <= 0 || H[i] <= 0 || W[i] <= 0) {
@@ -482,11 +526,13 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   static bool attr_set = false;
   if (!attr_set) {
     DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
+  const int tpw = (acc_mode == DIB_ACC_FP32) ? 1 : g_tpw;  // the fp32-accumulate kernel exists as <4, 1> only
   int i = 0;
   while (i < B) {
     BlurBatch tiled, generic;
@@ -497,7 +543,7 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       ImageDesc d;
       d.in = in_dev[i]; d.out = out_dev[i]; d.C = C[i]; d.H = H[i]; d.W = W[i]; d.table = table_index[i];
       d.tiles_x = (W[i] + TILE_W - 1) / TILE_W;
-      d.tiles_y = (H[i] + TH * g_tpw - 1) / (TH * g_tpw);
+      d.tiles_y = (H[i] + TH * tpw - 1) / (TH * tpw);
       d.tile_begin = tiles;
       tiled.tile_begin[tiled.n] = tiles;
       tiles += d.C * d.tiles_x * d.tiles_y;
@@ -527,7 +573,8 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     }
     if (dtype == DIB_F16) {
       for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
-      if (g_nw == 4 && g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1, true>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else if (g_nw == 4 && g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else if (g_nw == 4) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 2>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else if (g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 1>), dim3(grid), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 2>), dim3(grid), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
@@ -555,8 +602,10 @@ extern "C" int dib_sparse_blur_generic(const void *in_dev, void *out_dev, int C,
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DIB_F16)
     hipLaunchKernelGGL((blur_generic_kernel<__half, false>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
-  else
+  else if (dtype == DIB_F32)
     hipLaunchKernelGGL((blur_generic_kernel<float, false>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
+  else  // dtype 2: fp16 image, DIB_ACC_FP32 arithmetic
+    hipLaunchKernelGGL((blur_generic_kernel<__half, true>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }

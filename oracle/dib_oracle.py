@@ -320,8 +320,12 @@ def _pad_index(s, n, mode):
     return np.where((s < 0) | (s > n - 1), -1, s)
 
 
-def manual_blur(image, psf_norm):
+def manual_blur(image, psf_norm, fp32_accumulate=False):
     """models/blur_functions.py:11-69 (both canvas branches), post-ops excluded.
+
+    fp32_accumulate=True restates the library's DIB_ACC_FP32 mode instead of the reference
+    arithmetic (fp16 images only): the fp16 x fp16 products are exact in float32, the running sum is
+    float32, taps in the same order, one rounding to fp16 at the end.
 
     image: C x H x W float16 or float32;  psf_norm: K x K, same dtype, already normalised.
     out[ch,y,x] = sum over taps (r,c), row-major, of  rnd(rnd(P[(y+2pb-r) mod Hp, (x+2pb-c) mod Wp] * w) + acc)
@@ -346,7 +350,7 @@ def manual_blur(image, psf_norm):
     src_r = _pad_index(np.arange(Hp) - pb, H, mode)
     src_c = _pad_index(np.arange(Wp) - pb, W, mode)
     rows, cols, wts = taps_of(np.asarray(psf_norm).astype(dt))
-    acc = np.zeros((C, H, W), dtype=dt)                                   # :61
+    acc = np.zeros((C, H, W), dtype=np.float32 if fp32_accumulate else dt)   # :61
     ys, xs = np.arange(H), np.arange(W)
     for r, c, w in zip(rows, cols, wts):                                  # :66-67
         pr = src_r[(ys + 2 * pb - r) % Hp]
@@ -354,8 +358,11 @@ def manual_blur(image, psf_norm):
         g = image[:, np.maximum(pr, 0)][:, :, np.maximum(pc, 0)]
         if mode == "constant":
             g = g * ((pr >= 0)[None, :, None] & (pc >= 0)[None, None, :]).astype(dt)
-        acc = (acc + (g * dt.type(w)).astype(dt)).astype(dt)
-    out = acc
+        if fp32_accumulate:
+            acc = acc + g.astype(np.float32) * np.float32(w)
+        else:
+            acc = (acc + (g * dt.type(w)).astype(dt)).astype(dt)
+    out = acc.astype(dt)
     # :69 `.squeeze()` drops every size-1 dim
     return np.squeeze(out)
 

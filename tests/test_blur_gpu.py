@@ -193,6 +193,59 @@ def test_full_size_batch_vs_c_oracle_digest():
         assert torch.equal(batch[i], single)
 
 
+# ------------------------------------------------------------------ DIB_ACC_FP32 ("accurate" mode)
+
+ACC_FP32_TOL = 5e-3   # stated tolerance vs the reference's fp16 arithmetic (images in [0, 1], <= 272 taps;
+                      # scaled by the image's largest magnitude when that exceeds 1)
+
+
+@pytest.mark.parametrize("case", [c for c in GI.blur_cases() if not c.get("digest_only")], ids=lambda c: c["name"])
+def test_acc_fp32_mode_bit_exact_vs_oracle_and_within_tolerance_of_reference(golden, case):
+    """fp32-accumulate mode: bit-identical to its CPU restatement (exact products, fp32 sum, one
+    rounding) for the tiled AND the generic kernel, and within 5e-3 of the reference's result."""
+    from detectinblur_amd import _lib, blur_ops
+    from detectinblur_amd.models import blur_functions as BF
+    img = GI.make_image(case)
+    psf = GI.make_case_psf(case)
+    if img.dtype != np.float16:
+        with pytest.raises(_lib.DibError, match="fp16 images only"):
+            BF.manual_blur(_dev(img), _dev(psf), acc_mode=_lib.DIB_ACC_FP32)
+        return
+    want = O.manual_blur(img, psf, fp32_accumulate=True)
+    got = BF.manual_blur(_dev(img), _dev(psf), acc_mode=_lib.DIB_ACC_FP32).cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(want))
+    ref = golden.blur["blur_" + case["name"]].view(np.float16)
+    assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() <= ACC_FP32_TOL * max(1.0, float(np.abs(img).max()))
+    t_img = _dev(img)
+    tabs = blur_ops.compact_psfs([_dev(psf)], normalize=False)
+    out = torch.empty_like(t_img)
+    C, H, W = img.shape
+    _lib.check(_lib.lib().dib_sparse_blur_generic(t_img.data_ptr(), out.data_ptr(), C, H, W, 2, tabs.ptr(0), psf.shape[0],
+                                                  torch.cuda.current_stream().cuda_stream))
+    assert np.array_equal(_bits(out.cpu().numpy().squeeze()), _bits(want))
+
+
+def test_acc_fp32_mode_full_size_batch():
+    """configs[1] shape in fp32-accumulate mode: batch == per-image calls, one image checked against
+    the oracle on a strided sample of rows (the full oracle pass takes minutes at this size)."""
+    from detectinblur_amd import _lib
+    from detectinblur_amd.models import blur_functions as BF
+    imgs = [torch.rand(3, 800, 1333, generator=torch.Generator().manual_seed(1337 + i)).half().cuda() for i in range(8)]
+    psfs_h = [GI.golden_psf(0.005, i % 3, "half") for i in range(8)]
+    batch = list(imgs)
+    BF.blur_image_list(batch, [{"blurring": True}] * 8, [_dev(p) for p in psfs_h], acc_mode=_lib.DIB_ACC_FP32)
+    exact = list(imgs)
+    BF.blur_image_list(exact, [{"blurring": True}] * 8, [_dev(p) for p in psfs_h])
+    for i in range(8):
+        single = BF.manual_blur(imgs[i], _dev(O.normalize_psf(psfs_h[i])), acc_mode=_lib.DIB_ACC_FP32)
+        assert torch.equal(batch[i], single)
+        assert (batch[i].float() - exact[i].float()).abs().max().item() <= ACC_FP32_TOL
+    crop = imgs[3][:, 300:420, 500:760].cpu().numpy()            # interior crop: reflect padding of the crop
+    want = O.manual_blur(crop, O.normalize_psf(psfs_h[3]), fp32_accumulate=True)   # differs only near its border
+    got = batch[3][:, 300:420, 500:760].cpu().numpy()
+    assert np.array_equal(_bits(got[:, 64:-64, 64:-64]), _bits(want[:, 64:-64, 64:-64]))
+
+
 def test_segments_cover_taps_in_order_and_are_bounded():
     """The tap list is cut into consecutive segments of at most 17 rows x 33 columns."""
     from detectinblur_amd import blur_ops

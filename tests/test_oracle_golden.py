@@ -82,6 +82,24 @@ def test_manual_blur_bit_exact(golden, case):
     assert np.array_equal(_bits(out), want)
 
 
+# DIB_ACC_FP32 ("accurate" mode): fp32 running sum, one rounding.  Stated
+# tolerance against the reference's fp16 arithmetic: 5e-3 absolute for images in [0, 1] and <= 272 taps
+# (scaled by the image's largest magnitude when that exceeds 1).
+ACC_FP32_TOL = 5e-3
+
+
+@pytest.mark.parametrize("case", [c for c in GI.blur_cases() if not c.get("digest_only") and c.get("dtype", "float16") == "float16"],
+                         ids=lambda c: c["name"])
+def test_fp32_accumulate_mode_within_stated_tolerance(golden, case):
+    img = GI.make_image(case)
+    if img.dtype != np.float16:
+        pytest.skip("fp16 images only")
+    out = O.manual_blur(img, GI.make_case_psf(case), fp32_accumulate=True)
+    want = golden.blur["blur_" + case["name"]].view(np.float16)
+    assert out.dtype == np.float16 and out.shape == want.shape
+    assert np.abs(out.astype(np.float64) - want.astype(np.float64)).max() <= ACC_FP32_TOL * max(1.0, float(np.abs(img).max()))
+
+
 def test_manual_blur_coco_size_digest(golden):
     case = [c for c in GI.blur_cases() if c["name"] == "coco_e2_f16"][0]
     out = O.manual_blur(GI.make_image(case), GI.make_case_psf(case))
