@@ -16,6 +16,7 @@ Extra, optional key (ignored by reference-shaped consumers): `blur_dict["psf_ext
 """
 import copy
 import math
+import os
 import random
 
 import numpy as np
@@ -172,6 +173,24 @@ class BlurImage(object):
             return random.choices([0, 1, 2, 3, 4], weights=[0.0625, 0.0625, 0.0625, 0.375, 0.375])[0]
         return random.choice([0, 1, 2, 3, 4])
 
+    def _load_stored(self, param_index, fraction_index, psf_index):
+        """One stored PSF as a 128 x 128 float16 array: from the packed per-directory file written by
+        dataset_utils/generate_PSFs.py --packed when there is one (a memory-mapped row, no open() per
+        image), else from the reference's one-file-per-PSF layout (transforms.py:298-309)."""
+        key = (param_index, fraction_index)
+        packs = self.__dict__.setdefault("_packs", {})
+        if key not in packs:
+            packed = "%s/P%sE%s.npy" % (self.stored_psf_directory, param_index, fraction_index)
+            packs[key] = np.load(packed, mmap_mode="r") if os.path.isfile(packed) else None
+        if packs[key] is not None and psf_index < packs[key].shape[0]:
+            return np.array(packs[key][psf_index])
+        path = "%s/P%sE%s/I%06d" % (self.stored_psf_directory, param_index, fraction_index, psf_index)
+        with open(path, "rb") as f:
+            psf = np.load(f)
+        if psf.shape[0] > 128:
+            psf = psf[64:128 + 64, 64:128 + 64]
+        return psf
+
     def __call__(self, image, target=None, blur_dict={}):
         if "preBlurred" in blur_dict and blur_dict["preBlurred"]:      # reference :225-235
             return image, target, self._not_blurred(blur_dict, with_inverse_warp=True)
@@ -202,11 +221,7 @@ class BlurImage(object):
             else:
                 fraction_index = self._exposure_index(stored=True)
             psf_index = random.randint(0, self.stored_psf_count - 1)
-            path = "%s/P%sE%s/I%06d" % (self.stored_psf_directory, param_index, fraction_index, psf_index)
-            with open(path, "rb") as f:
-                psf = np.load(f)
-            if psf.shape[0] > 128:
-                psf = psf[64:128 + 64, 64:128 + 64]
+            psf = self._load_stored(param_index, fraction_index, psf_index)
         else:                                                           # :316-335
             psf = make_psf(param, fraction, center=not self.dont_center_psf)
 

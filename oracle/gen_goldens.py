@@ -215,10 +215,46 @@ def gen_fft(ns, store):
     store["fft_out"] = np.array(h.pilImageResult)
 
 
+PSF_STORE_RUNS = {"w0_of1_n2": (0, 1, 2), "w1_of2_n4": (1, 2, 4)}   # name -> (worker_index, num_workers, total_num_psfs)
+
+
+def gen_psf_store(ns, meta):
+    """Runs the reference's dataset_utils/generate_PSFs.py main() into a temp dir and records the
+    SHA-256 of every file it writes (15 directories x slice): the store builder must reproduce the
+    files byte for byte."""
+    import argparse
+    import importlib
+    import shutil
+    import tempfile
+    ref = importlib.import_module("dataset_utils.generate_PSFs")
+    out = {}
+    for name, (w, nw, tot) in PSF_STORE_RUNS.items():
+        d = tempfile.mkdtemp() + "/"
+        ref.main(argparse.Namespace(destination_path=d, worker_index=w, num_workers=nw, total_num_psfs=tot))
+        digests = {}
+        for root, _, files in os.walk(d + "psfs"):
+            for fn in files:
+                full = os.path.join(root, fn)
+                with open(full, "rb") as f:
+                    digests[os.path.relpath(full, d)] = hashlib.sha256(f.read()).hexdigest()
+        out[name] = digests
+        shutil.rmtree(d)
+    meta["psf_store"] = out
+
+
 def main():
     ns = ref_harness.load()
     os.makedirs(OUT, exist_ok=True)
+    if "--only-psf-store" in sys.argv:      # incremental: adds one key to the committed meta.json
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        gen_psf_store(ns, meta)
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print("psf_store:", {k: len(v) for k, v in meta["psf_store"].items()})
+        return
     meta = {"numpy": np.__version__, "torch": torch.__version__}
+    gen_psf_store(ns, meta)
     for name, fn in (("traj", gen_trajectories), ("psf", gen_psfs), ("boxes", gen_boxes),
                      ("norm", gen_norm), ("fft", gen_fft)):
         store = {}
