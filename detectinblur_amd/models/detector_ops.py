@@ -99,8 +99,8 @@ class Matcher(object):
         if self.allow_low:
             # every ground truth keeps the prediction(s) it overlaps best, however poorly
             best_per_gt = quality.max(dim=1)[0]
-            restore = torch.where(quality == best_per_gt[:, None])[1]
-            matches[restore] = all_matches[restore]
+            restore = (quality == best_per_gt[:, None]).any(dim=0)       # a mask, not torch.where: no host sync
+            matches = torch.where(restore, all_matches, matches)
         return matches
 
 
@@ -117,6 +117,26 @@ def sample_pos_neg(labels_per_image, batch_size, positive_fraction):
         neg = neg[torch.randperm(neg.numel(), device=neg.device)[:n_neg]]
         out.append((pos, neg))
     return out
+
+
+def sample_pos_neg_fixed(labels, batch_size, positive_fraction):
+    """The same sampling rule without data-dependent shapes (hence without host synchronisation):
+    labels [N, A] (>= 1 positive, 0 negative, < 0 ignored).  Per row, a uniformly random subset of
+    min(#pos, P) positives, P = int(batch_size * positive_fraction), and a uniformly random subset of
+    min(#neg, batch_size - n_pos) negatives -- drawn as the smallest of i.i.d. uniform keys instead of
+    a randperm prefix.  Returns (pos_idx [N, P'], pos_ok [N, P'], neg_idx [N, B'], neg_ok [N, B']);
+    entries whose `ok` flag is False are padding and must be masked by the caller."""
+    N, A = labels.shape
+    P = min(int(batch_size * positive_fraction), A)
+    Bn = min(batch_size, A)
+    keys = torch.rand((2, N, A), device=labels.device)
+    far = 2.0
+    vp, pos_idx = torch.where(labels >= 1, keys[0], far).topk(P, dim=1, largest=False, sorted=True)
+    pos_ok = vp < far
+    n_pos = pos_ok.sum(dim=1, keepdim=True)
+    vn, neg_idx = torch.where(labels == 0, keys[1], far).topk(Bn, dim=1, largest=False, sorted=True)
+    neg_ok = (vn < far) & (torch.arange(Bn, device=labels.device)[None, :] < (batch_size - n_pos))
+    return pos_idx, pos_ok, neg_idx, neg_ok
 
 
 # ------------------------------------------------------------------------------------------------

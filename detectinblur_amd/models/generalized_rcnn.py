@@ -31,7 +31,7 @@ class GeneralizedRCNN(nn.Module):
         original_sizes = [(int(img.shape[-2]), int(img.shape[-1])) for img in images]
         images, targets = self.transform(images, targets, newMeans, newSTDs)
         # degenerate-box check (reference generalized_rcnn.py:119-129): the flags are computed here, on
-        # the device, but READ only after the backbone and the RPN have been enqueued -- reading them first would
+        # the device, but READ only once the whole forward pass has been enqueued -- reading them first would
         # stall the host behind the previous step's backward and leave the GPU idle while the
         # forward pass is issued.  Same ValueError, raised before anything is returned.
         degenerate = None
@@ -42,6 +42,8 @@ class GeneralizedRCNN(nn.Module):
         if isinstance(features, torch.Tensor):
             features = OrderedDict([("0", features)])
         proposals, proposal_losses = self.rpn(images, features, targets)
+        detections, detector_losses = self.roi_heads(features, proposals, images.image_sizes, targets)
+        detections = self.transform.postprocess(detections, images.image_sizes, original_sizes)
         if degenerate is not None and bool(degenerate.any()):
             for idx, target in enumerate(targets):
                 boxes = target["boxes"]
@@ -50,8 +52,6 @@ class GeneralizedRCNN(nn.Module):
                     bb = boxes[bad.any(dim=1).nonzero().view(-1)[0]].tolist()
                     raise ValueError("All bounding boxes should have positive height and width."
                                      " Found invaid box {} for target at index {}.".format(bb, idx))
-        detections, detector_losses = self.roi_heads(features, proposals, images.image_sizes, targets)
-        detections = self.transform.postprocess(detections, images.image_sizes, original_sizes)
         if self.training:
             losses = {}
             losses.update(detector_losses)

@@ -29,13 +29,28 @@ class FastRCNNPredictor(nn.Module):
         return self.cls_score(x), self.bbox_pred(x)
 
 
-def fastrcnn_loss(class_logits, box_regression, labels, regression_targets):
-    labels = torch.cat(labels)
-    regression_targets = torch.cat(regression_targets)
-    cls_loss = F.cross_entropy(class_logits, labels)
-    pos = torch.where(labels > 0)[0]
-    box_regression = box_regression.reshape(class_logits.shape[0], -1, 4)
-    box_loss = F.smooth_l1_loss(box_regression[pos, labels[pos]], regression_targets[pos], beta=1 / 9, reduction="sum") / max(labels.numel(), 1)
+def _unit_boxes(n, like):
+    """n x [0, 0, 1, 1] padding boxes, built from fill kernels (a `new_tensor([...])` literal would be a
+    blocking host-to-device copy in the middle of the forward pass)."""
+    return torch.cat((like.new_zeros((n, 2)), like.new_ones((n, 2))), dim=1)
+
+
+def fastrcnn_loss(class_logits, box_regression, labels, regression_targets, ok=None):
+    """labels [M] int64, regression_targets [M, 4]; `ok` [M] bool masks padding rows of the fixed-size
+    sampler (None = every row counts).  Classification: mean cross-entropy over the sampled RoIs;
+    boxes: smooth-L1 sum over sampled foreground RoIs / number sampled."""
+    if isinstance(labels, (list, tuple)):
+        labels, regression_targets = torch.cat(labels), torch.cat(regression_targets)
+    M = labels.shape[0]
+    if ok is None:
+        ok = torch.ones_like(labels, dtype=torch.bool)
+    n = ok.sum().clamp(min=1)
+    safe = labels.clamp(min=0)
+    ce = F.cross_entropy(class_logits, safe, reduction="none")
+    cls_loss = torch.where(ok, ce, ce.new_zeros(())).sum() / n
+    per_class = box_regression.reshape(M, -1, 4).gather(1, safe[:, None, None].expand(-1, 1, 4)).squeeze(1)
+    l1 = F.smooth_l1_loss(per_class, regression_targets, beta=1 / 9, reduction="none")
+    box_loss = torch.where((ok & (labels > 0))[:, None], l1, l1.new_zeros(())).sum() / n
     return cls_loss, box_loss
 
 
@@ -50,31 +65,55 @@ class RoIHeads(nn.Module):
         self.score_thresh, self.nms_thresh, self.detections_per_img = score_thresh, nms_thresh, detections_per_img
 
     def select_training_samples(self, proposals, targets):
-        gt_boxes = [t["boxes"].to(proposals[0].dtype) for t in targets]
+        """proposals: (boxes [N, P, 4], ok [N, P]) from the RPN's padded training output, or a list of
+        [P_i, 4] tensors.  Ground truth joins the pool, every candidate is labelled by IoU matching,
+        and `batch_size_per_image` RoIs are drawn per image (<= positive_fraction foreground).
+        Everything has a fixed shape -- [N, batch_size_per_image] -- so nothing waits on the device;
+        `ok` marks the rows that are real samples (all of them unless an image is short of candidates).
+        Returns (list of [S, 4] RoIs, labels [N*S], regression targets [N*S, 4], ok [N*S])."""
+        if isinstance(proposals, (list, tuple)) and not (len(proposals) == 2 and proposals[1].dtype == torch.bool):
+            width = max(p.shape[0] for p in proposals)
+            boxes = torch.stack([torch.cat((p, _unit_boxes(width - p.shape[0], p))) for p in proposals])
+            ok = torch.stack([torch.arange(width, device=p.device) < p.shape[0] for p in proposals])
+        else:
+            boxes, ok = proposals
+        dtype, device = boxes.dtype, boxes.device
+        gt_boxes = [t["boxes"].to(dtype) for t in targets]
         gt_labels = [t["labels"] for t in targets]
-        proposals = [torch.cat((p, g)) for p, g in zip(proposals, gt_boxes)]      # ground truth joins the pool
-        labels, matched_idx = [], []
-        for p, g, gl in zip(proposals, gt_boxes, gt_labels):
-            if g.numel() == 0:
-                matched_idx.append(torch.zeros((p.shape[0],), dtype=torch.int64, device=p.device))
-                labels.append(torch.zeros((p.shape[0],), dtype=torch.int64, device=p.device))
-                continue
-            m = self.matcher(ops.box_iou(g, p))
-            lab = gl[m.clamp(min=0)].to(torch.int64)
-            lab[m == ops.Matcher.BELOW_LOW] = 0
-            lab[m == ops.Matcher.BETWEEN] = -1
-            matched_idx.append(m.clamp(min=0))
-            labels.append(lab)
-        picks = ops.sample_pos_neg(labels, self.batch_size_per_image, self.positive_fraction)
-        out_p, out_l, out_t = [], [], []
-        for (pos, neg), p, lab, mi, g in zip(picks, proposals, labels, matched_idx, gt_boxes):
-            idx = torch.cat([pos, neg])
-            p, lab = p[idx], lab[idx]
-            g = g if g.numel() else torch.zeros((1, 4), dtype=p.dtype, device=p.device)
-            out_p.append(p)
-            out_l.append(lab)
-            out_t.append(self.box_coder.encode(g[mi[idx]], p))
-        return out_p, out_l, out_t
+        g_max = max([g.shape[0] for g in gt_boxes] + [1])
+        cands, labels, matched = [], [], []
+        for b, o, g, gl in zip(boxes, ok, gt_boxes, gt_labels):
+            G = g.shape[0]
+            pad = g_max - G
+            filler = _unit_boxes(pad, b)
+            cand = torch.cat((b, g, filler))                                   # ground truth joins the pool
+            live = torch.cat((o, o.new_ones(G), o.new_zeros(pad)))
+            if G == 0:
+                m = torch.zeros((cand.shape[0],), dtype=torch.int64, device=device)
+                lab = torch.zeros((cand.shape[0],), dtype=torch.int64, device=device)
+            else:
+                m = self.matcher(ops.box_iou(g, cand))
+                lab = gl[m.clamp(min=0)].to(torch.int64)
+                lab = torch.where(m == ops.Matcher.BELOW_LOW, lab.new_zeros(()), lab)
+                lab = torch.where(m == ops.Matcher.BETWEEN, lab.new_full((), -1), lab)
+            cands.append(cand)
+            labels.append(torch.where(live, lab, lab.new_full((), -1)))         # padding is ignored by the sampler
+            matched.append(m.clamp(min=0))
+        cands, labels, matched = torch.stack(cands), torch.stack(labels), torch.stack(matched)
+        S = self.batch_size_per_image
+        pos_idx, pos_ok, neg_idx, neg_ok = ops.sample_pos_neg_fixed(labels, S, self.positive_fraction)
+        sel, sel_ok = torch.cat([pos_idx, neg_idx], dim=1), torch.cat([pos_ok, neg_ok], dim=1)
+        # real samples first (foreground, then background, each in draw order), padding last; keep S
+        order = torch.argsort((~sel_ok).to(torch.int8), dim=1, stable=True)[:, :S]
+        sel, sel_ok = sel.gather(1, order), sel_ok.gather(1, order)
+        rois = cands.gather(1, sel[..., None].expand(-1, -1, 4))
+        labs = labels.gather(1, sel)
+        midx = matched.gather(1, sel)
+        reg = []
+        for r, mi, g in zip(rois, midx, gt_boxes):
+            g = g if g.numel() else torch.zeros((1, 4), dtype=dtype, device=device)
+            reg.append(self.box_coder.encode(g[mi], r))
+        return list(rois), labs.reshape(-1), torch.cat(reg), sel_ok.reshape(-1)
 
     def postprocess_detections(self, class_logits, box_regression, proposals, image_shapes):
         num_classes = class_logits.shape[-1]
@@ -96,10 +135,10 @@ class RoIHeads(nn.Module):
 
     def forward(self, features, proposals, image_shapes, targets=None):
         if self.training:
-            proposals, labels, reg_targets = self.select_training_samples(proposals, targets)
+            proposals, labels, reg_targets, ok = self.select_training_samples(proposals, targets)
         box_features = self.box_head(self.box_roi_pool(features, proposals, image_shapes))
         class_logits, box_regression = self.box_predictor(box_features)
         if self.training:
-            cls, box = fastrcnn_loss(class_logits, box_regression, labels, reg_targets)
+            cls, box = fastrcnn_loss(class_logits, box_regression, labels, reg_targets, ok)
             return [], {"loss_classifier": cls, "loss_box_reg": box}
         return self.postprocess_detections(class_logits, box_regression, proposals, image_shapes), {}

@@ -95,7 +95,7 @@ class RegionProposalNetwork(nn.Module):
     def _n(self, d):
         return d["training"] if self.training else d["testing"]
 
-    def filter_proposals(self, proposals, objectness, image_sizes, counts):
+    def filter_proposals(self, proposals, objectness, image_sizes, counts, padded=False):
         N = proposals.shape[0]
         objectness = objectness.detach().reshape(N, -1)
         levels = torch.cat([torch.full((n,), i, dtype=torch.int64, device=proposals.device) for i, n in enumerate(counts)])
@@ -130,6 +130,11 @@ class RegionProposalNetwork(nn.Module):
         keep = keep[:, :post]
         boxes = boxes.gather(1, keep[..., None].expand(-1, -1, 4))
         scores = scores.gather(1, keep)
+        if padded:
+            # training: fixed [N, post, 4] + validity mask, no host synchronisation at all (rows past
+            # the kept count repeat the image's best box and are masked by every consumer)
+            ok = torch.arange(keep.shape[1], device=keep.device)[None, :] < count.clamp(max=post)[:, None]
+            return (boxes, ok), scores
         counts_host = count.clamp(max=post).tolist()        # the one synchronisation point
         boxes_out = [boxes[i, :c] for i, c in enumerate(counts_host)]
         scores_out = [scores[i, :c] for i, c in enumerate(counts_host)]
@@ -152,17 +157,19 @@ class RegionProposalNetwork(nn.Module):
         return labels, matched
 
     def compute_loss(self, objectness, deltas, labels, regression_targets):
-        picks = ops.sample_pos_neg(labels, self.batch_size_per_image, self.positive_fraction)
-        offs, pos_all, all_idx = 0, [], []
-        for (pos, neg), lab in zip(picks, labels):
-            pos_all.append(pos + offs)
-            all_idx.append(torch.cat([pos, neg]) + offs)
-            offs += lab.numel()
-        pos_all, all_idx = torch.cat(pos_all), torch.cat(all_idx)
-        objectness = objectness.flatten()
-        labels, regression_targets = torch.cat(labels), torch.cat(regression_targets)
-        box_loss = F.smooth_l1_loss(deltas[pos_all], regression_targets[pos_all], beta=1 / 9, reduction="sum") / max(all_idx.numel(), 1)
-        obj_loss = F.binary_cross_entropy_with_logits(objectness[all_idx], labels[all_idx])
+        """labels [N, A] (1 / 0 / -1), regression_targets [N, A, 4].  Fixed-size sampling + masked
+        sums: the same losses as gathering a ragged index list (objectness: mean BCE over the sampled
+        anchors; boxes: smooth-L1 sum over sampled positives / number sampled), with no host sync."""
+        N, A = labels.shape
+        pos_idx, pos_ok, neg_idx, neg_ok = ops.sample_pos_neg_fixed(labels, self.batch_size_per_image, self.positive_fraction)
+        sel, ok = torch.cat([pos_idx, neg_idx], dim=1), torch.cat([pos_ok, neg_ok], dim=1)
+        n_sel = ok.sum().clamp(min=1)
+        obj = objectness.reshape(N, A).gather(1, sel)
+        bce = F.binary_cross_entropy_with_logits(obj, labels.gather(1, sel), reduction="none")
+        obj_loss = torch.where(ok, bce, bce.new_zeros(())).sum() / n_sel
+        g = pos_idx[..., None].expand(-1, -1, 4)
+        l1 = F.smooth_l1_loss(deltas.reshape(N, A, 4).gather(1, g), regression_targets.gather(1, g), beta=1 / 9, reduction="none")
+        box_loss = torch.where(pos_ok[..., None], l1, l1.new_zeros(())).sum() / n_sel
         return obj_loss, box_loss
 
     def forward(self, images, features, targets=None):
@@ -173,12 +180,12 @@ class RegionProposalNetwork(nn.Module):
         objectness, deltas = _flatten_levels(logits, deltas)
         N = len(anchors)
         proposals = self.box_coder.decode(deltas.detach(), torch.cat(anchors)).view(N, -1, 4)
-        boxes, _ = self.filter_proposals(proposals, objectness, images.image_sizes, counts)
+        boxes, _ = self.filter_proposals(proposals, objectness, images.image_sizes, counts, padded=self.training)
         losses = {}
         if self.training:
             assert targets is not None
             labels, matched = self.assign_targets(anchors, targets)
             reg_targets = [self.box_coder.encode(m, a) for m, a in zip(matched, anchors)]
-            obj, box = self.compute_loss(objectness, deltas, labels, reg_targets)
+            obj, box = self.compute_loss(objectness, deltas, torch.stack(labels), torch.stack(reg_targets))
             losses = {"loss_objectness": obj, "loss_rpn_box_reg": box}
         return boxes, losses

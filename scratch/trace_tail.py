@@ -35,3 +35,15 @@ for s, e, n in win[1:]:
 print("\nidle %.1f ms in window; gaps > 20 us by (kernel before -> kernel after):" % (idle / 1e6))
 for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:30]:
     print("%8.2f ms %5d x  %s  ->  %s" % (t / 1e6, c, a, b))
+
+# ---- per-step accounting: one blur_tiled launch marks the start of each step -----------------------------
+marks = [s for s, e, n in rows if "blur_tiled" in n]
+if len(marks) >= 4:
+    print("\nper-step (delimited by blur launches): span / kernel-busy / idle / launches")
+    for a, b in zip(marks[-4:-1], marks[-3:]):
+        ks = [(s, e) for s, e, n in rows if a <= s < b]
+        busy, cur = 0, a
+        for s, e in ks:
+            s2 = max(s, cur)
+            if e > s2: busy += e - s2; cur = e
+        print("  %.1f ms  busy %.1f ms  idle %.1f ms  %d launches" % ((b - a) / 1e6, busy / 1e6, (b - a - busy) / 1e6, len(ks)))

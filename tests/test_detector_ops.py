@@ -85,6 +85,59 @@ def test_box_coder_roundtrip_and_matcher():
     assert ops.Matcher(0.7, 0.3, True)(q.clone()).tolist() == [0, 1, -1, -2]
 
 
+def test_fixed_size_sampler_follows_the_sampling_rule():
+    """sample_pos_neg_fixed: per row min(#pos, P) positives and min(#neg, B - n_pos) negatives, all
+    drawn from the right sets, no duplicates -- the rule of sample_pos_neg without ragged outputs."""
+    torch.manual_seed(0)
+    rows = [(300, 5000), (10, 5000), (0, 400), (200, 30), (0, 0)]          # (#pos, #neg) of 6000 entries
+    labels = torch.full((len(rows), 6000), -1.0)
+    for i, (npos, nneg) in enumerate(rows):
+        perm = torch.randperm(6000)
+        labels[i, perm[:npos]] = 1.0
+        labels[i, perm[npos:npos + nneg]] = 0.0
+    B, frac = 256, 0.5
+    pos_idx, pos_ok, neg_idx, neg_ok = ops.sample_pos_neg_fixed(labels, B, frac)
+    assert pos_idx.shape == (len(rows), 128) and neg_idx.shape == (len(rows), 256)
+    for i, (npos, nneg) in enumerate(rows):
+        p, n = pos_idx[i][pos_ok[i]], neg_idx[i][neg_ok[i]]
+        n_pos = min(npos, int(B * frac))
+        assert p.numel() == n_pos and n.numel() == min(nneg, B - n_pos)
+        assert (labels[i, p] == 1).all() and (labels[i, n] == 0).all()
+        assert p.unique().numel() == p.numel() and n.unique().numel() == n.numel()
+    # different draws pick different subsets, each entry about equally often
+    hits = torch.zeros(6000)
+    for _ in range(200):
+        pi, po, _, _ = ops.sample_pos_neg_fixed(labels[:1], B, frac)
+        hits[pi[0][po[0]]] += 1
+    chosen = hits[labels[0] == 1]
+    assert chosen.min() > 40 and chosen.max() < 140        # expectation 200 * 128 / 300 = 85
+
+
+def test_masked_fastrcnn_loss_equals_the_ragged_form():
+    from detectinblur_amd.models.roi_heads import fastrcnn_loss
+    torch.manual_seed(1)
+    M, C = 40, 7
+    logits, reg = torch.randn(M, C), torch.randn(M, C * 4)
+    labels = torch.randint(0, C, (M,))
+    targets = torch.randn(M, 4)
+    ok = torch.rand(M) > 0.3
+    cls_m, box_m = fastrcnn_loss(logits, reg, torch.where(ok, labels, torch.full_like(labels, -1)),
+                                 torch.where(ok[:, None], targets, torch.full_like(targets, float("nan"))), ok)
+    keep = torch.where(ok)[0]
+    l, r, t = labels[keep], reg[keep].reshape(-1, C, 4), targets[keep]
+    pos = torch.where(l > 0)[0]
+    cls_r = torch.nn.functional.cross_entropy(logits[keep], l)
+    box_r = torch.nn.functional.smooth_l1_loss(r[pos, l[pos]], t[pos], beta=1 / 9, reduction="sum") / l.numel()
+    assert torch.allclose(cls_m, cls_r, atol=1e-6) and torch.allclose(box_m, box_r, atol=1e-6)
+
+
+def test_matcher_low_quality_restore_without_sync():
+    q = torch.tensor([[0.1, 0.6, 0.2, 0.05], [0.3, 0.2, 0.25, 0.05]])
+    m = ops.Matcher(0.7, 0.3, allow_low_quality_matches=True)(q)
+    # column 1 is gt 0's best (0.6, between thresholds -> restored to 0); column 0 is gt 1's best (0.3)
+    assert m.tolist() == [1, 0, ops.Matcher.BELOW_LOW, ops.Matcher.BELOW_LOW]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,scale", [((2, 16, 50, 68), 0.25), ((1, 256, 25, 34), 0.125), ((3, 8, 7, 9), 1 / 32)])
 def test_roi_align_hip_forward_backward(shape, scale):
