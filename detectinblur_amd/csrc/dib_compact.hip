@@ -114,9 +114,13 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   // ---- sum ------------------------------------------------------------------------------------
   T total = T(1.0f);
   if (normalize & 1) {
+    // A PSF is a thin curve: of the 64 x EPT elements a wave holds, a few dozen are non-zero.  Zeros
+    // add nothing, so element slots that are zero in every lane are skipped with one ballot
+    // (lifting and dividing all 16,384 elements used to be a third of this kernel's time).
     typename E::Acc acc = 0;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) acc += E::lift(v[i]);
+    for (int i = 0; i < EPT; ++i)
+      if (__builtin_amdgcn_ballot_w64(E::nonzero(v[i])) != 0) acc += E::lift(v[i]);
     acc = wave_sum(acc);
     if (lane == 0) s_part[wave] = acc;
     __syncthreads();
@@ -135,8 +139,12 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   unsigned long long mask = 0;
   int rmin = K, rmax = -1, cmin = K, cmax = -1;
   const int e0 = tid * EPT;
+  // 0 / total is 0 unless total is 0 or NaN (then the reference's psf / psf.sum() is NaN everywhere and
+  // every element becomes a tap): only in that case are all-zero slots divided too
+  const bool sane = (float)total == (float)total && E::nonzero(total);
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
+    if (sane && __builtin_amdgcn_ballot_w64(E::nonzero(v[i])) == 0) continue;
     if (normalize & 1) v[i] = E::div(v[i], total);
     if (E::nonzero(v[i])) {
       mask |= 1ull << i;

@@ -80,6 +80,25 @@ def test_half_sum_is_exactly_rounded():
         assert np.array_equal((w.numpy() & 0xffff).astype(np.uint16), ww.view(np.uint16))
 
 
+def test_all_zero_psf_normalises_to_nan_taps_like_the_reference():
+    """psf / psf.sum() of an all-zero PSF is NaN everywhere and NaN counts as non-zero (torch.nonzero):
+    16,384 taps.  Also a PSF whose tiny entries underflow to zero in the division loses those taps."""
+    from detectinblur_amd import blur_ops
+    tabs = blur_ops.compact_psfs([_dev(np.zeros((128, 128), np.float16))], normalize=True)
+    assert tabs.header(0)[0] == 128 * 128
+    r, c, w = tabs.taps(0)
+    assert np.array_equal(r.numpy(), np.repeat(np.arange(128), 128)) and np.array_equal(c.numpy(), np.tile(np.arange(128), 128))
+    assert np.isnan((w.numpy() & 0xffff).astype(np.uint16).view(np.float16)).all()
+    a = np.zeros((128, 128), np.float16)
+    a[60, 60] = 60000.0; a[61, 61] = 6e-8; a[70, 3] = 1.0          # 6e-8 / 60000 underflows to 0 in fp16
+    tabs = blur_ops.compact_psfs([_dev(a)], normalize=True)
+    rr, cc, ww = O.taps_of(O.normalize_psf(a))
+    r, c, w = tabs.taps(0)
+    assert list(zip(rr.tolist(), cc.tolist())) == [(60, 60), (70, 3)]
+    assert np.array_equal(r.numpy(), rr) and np.array_equal(c.numpy(), cc)
+    assert np.array_equal((w.numpy() & 0xffff).astype(np.uint16), ww.view(np.uint16))
+
+
 # ------------------------------------------------------------------ manual_blur vs golden + oracle
 
 @pytest.mark.parametrize("case", GI.blur_cases(), ids=lambda c: c["name"])
