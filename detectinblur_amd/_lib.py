@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 
 DIB_F16, DIB_F32 = 0, 1
 DIB_ACC_BITEXACT, DIB_ACC_FP32 = 0, 1
-DIB_ESHAPE, DIB_ENOT128 = -2, -4
+DIB_EINVAL, DIB_ESHAPE, DIB_EHIP, DIB_ENOT128 = -1, -2, -3, -4
 
 _lib = None
 

@@ -1,0 +1,68 @@
+"""The C ABI: both shared libraries load on a machine without a GPU and export every entry point
+that include/dib.h and include/dib_host.h declare (no compute calls here), the Python signature
+tables cover exactly that set, and the product package never imports the oracle."""
+import ast
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dib_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_device_library_exports_every_declared_symbol():
+    from detectinblur_amd import _lib
+    names = _declared("dib.h")
+    assert len(names) >= 18
+    l = _lib.lib()
+    for n in names:
+        assert getattr(l, n) is not None, n
+    assert sorted(_lib.EXPORTS) == names          # every declared entry point has a ctypes signature, and nothing else
+    assert l.dib_abi_version() == 1
+    assert l.dib_tap_table_bytes(128) > 0 and l.dib_tap_table_bytes(100) == 0
+    assert l.dib_tap_tables_bytes(128, 8) == 8 * l.dib_tap_table_bytes(128) + 1024
+    assert l.dib_nms_workspace_bytes(128) == 128 * 2 * 8
+
+
+def test_host_library_exports_every_declared_symbol():
+    from detectinblur_amd import _hostlib
+    names = _declared("dib_host.h")
+    h = _hostlib.lib()
+    for n in names:
+        assert getattr(h, n) is not None, n
+    assert set(_hostlib.EXPORTS) == set(names)
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from detectinblur_amd import _lib
+    l = _lib.lib()
+    assert l.dib_psf_compact(None, 0, 1, 128, 1, None, None) == _lib.DIB_EINVAL
+    assert b"null pointer" in l.dib_last_error()
+    assert l.dib_nms(None, 70000, 0.5, None, None, None, None) == _lib.DIB_EINVAL
+    assert b"16384" in l.dib_last_error()
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+    may touch it."""
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "detectinblur_amd")):
+        for fn in files:
+            if not fn.endswith(".py"):
+                continue
+            src = open(os.path.join(d, fn)).read()
+            for node in ast.walk(ast.parse(src)):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom) and node.module:
+                    mods = [node.module]
+                if any(m.split(".")[0] in ("oracle", "dib_oracle", "ref_harness", "golden_inputs", "gen_goldens") for m in mods):
+                    bad.append(os.path.join(d, fn))
+            if "oracle" in src and ("sys.path" in src and "oracle" in src.split("sys.path")[1][:200]):
+                bad.append(os.path.join(d, fn) + " (sys.path)")
+    assert not bad, bad
