@@ -8,3 +8,15 @@ All device work goes through the C ABI of include/dib.h (libdib_hip.so, hand-wri
 gfx950); there is no CPU fallback.
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# MIOpen picks each convolution's kernel by timing every applicable solver the first time it sees a
+# shape (~90 s for this detector at b=8 x 800x1344 on a fresh machine) and remembers the result in a
+# "user find-db".  `miopen_db/` ships that database for the BASELINE shapes on gfx950, so a fresh
+# process warms up in about a second; unknown shapes are tuned as usual and appended.  Respect an
+# explicit MIOPEN_USER_DB_PATH; DIB_NO_MIOPEN_DB=1 opts out.  Must run before the first convolution.
+if not _os.environ.get("DIB_NO_MIOPEN_DB"):
+    _db = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+    if _os.path.isdir(_db) and _os.access(_db, _os.W_OK):
+        _os.environ.setdefault("MIOPEN_USER_DB_PATH", _db)
