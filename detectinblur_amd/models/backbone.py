@@ -45,12 +45,61 @@ class FrozenBatchNorm2d(nn.Module):
 FOLD_FROZEN_BN = True
 
 
-def conv_bn(x, conv, bn):
+class _BiasAct(torch.autograd.Function):
+    """x = act(x + bias[c] (+ residual)) in place on a channels-last fp32 CUDA tensor, one HIP launch
+    (include/dib.h: dib_bias_act_nhwc).  Backward: ReLU mask from the saved output (one stock pass);
+    the same gradient flows to x and to the residual; the bias gradient is a channel sum when asked for."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, relu):
+        from .. import _lib
+        N, C, H, W = x.shape
+        _lib.check(_lib.lib().dib_bias_act_nhwc(x.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                                x.numel(), C, int(relu), torch.cuda.current_stream().cuda_stream))
+        ctx.mark_dirty(x)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        if relu:
+            ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, grad):
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            grad = torch.ops.aten.threshold_backward(grad, y, 0)
+        gb = grad.sum(dim=(0, 2, 3)) if ctx.needs_input_grad[1] else None
+        return grad, gb, (grad if ctx.has_res else None), None
+
+
+def bias_act(x, bias, residual=None, relu=True):
+    """act(x + bias[:, None, None] (+ residual)); fused and in place for channels-last fp32 CUDA tensors
+    fresh out of a convolution, plain torch ops otherwise."""
+    fast = (FUSE_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] > 1
+            and x.is_contiguous(memory_format=torch.channels_last) and bias.dtype == torch.float32
+            and (residual is None or (residual.shape == x.shape and residual.dtype == torch.float32
+                                      and residual.is_contiguous(memory_format=torch.channels_last))))
+    if fast:
+        return _BiasAct.apply(x, bias.contiguous(), residual, relu)
+    y = x + bias.reshape(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+FUSE_EPILOGUE = True
+
+
+def conv_bn(x, conv, bn, relu=False, residual=None):
+    """conv -> frozen batch-norm (-> + residual) (-> ReLU).  With FOLD_FROZEN_BN the norm's scale goes
+    into the weights and its shift into the fused epilogue."""
     if FOLD_FROZEN_BN and isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
         scale, shift = bn.affine()
-        return F.conv2d(x, conv.weight * scale.reshape(-1, 1, 1, 1), shift, conv.stride, conv.padding, conv.dilation,
-                        conv.groups)
-    return bn(conv(x))
+        y = F.conv2d(x, conv.weight * scale.reshape(-1, 1, 1, 1), None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return bias_act(y, shift, residual, relu)
+    y = bn(conv(x))
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
 
 
 class Bottleneck(nn.Module):
@@ -68,10 +117,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
-        out = F.relu(conv_bn(x, self.conv1, self.bn1))
-        out = F.relu(conv_bn(out, self.conv2, self.bn2))
-        out = conv_bn(out, self.conv3, self.bn3)
-        return F.relu(out + idt)
+        out = conv_bn(x, self.conv1, self.bn1, relu=True)
+        out = conv_bn(out, self.conv2, self.bn2, relu=True)
+        return conv_bn(out, self.conv3, self.bn3, relu=True, residual=idt)
 
 
 class ResNet50Body(nn.Module):
@@ -96,7 +144,7 @@ class ResNet50Body(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(conv_bn(x, self.conv1, self.bn1)), 3, stride=2, padding=1)
+        x = F.max_pool2d(conv_bn(x, self.conv1, self.bn1, relu=True), 3, stride=2, padding=1)
         c2 = self.layer1(x)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)

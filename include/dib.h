@@ -153,6 +153,15 @@ int dib_nms_batched(const float *boxes_sorted_dev, const unsigned char *valid_de
                     float iou_threshold, void *workspace_dev, long long *keep_dev, int *count_dev,
                     void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Convolution epilogue of the ResNet-50 trunk with its frozen batch-norm folded into the weights
+ * (reference models/faster_rcnn.py:367 builds the trunk with torchvision's FrozenBatchNorm2d):
+ *   x = act(x + bias[c] (+ residual)), in place, channels-last fp32 (channel index fastest);
+ * one pass instead of eager PyTorch's 2-4.  residual_dev may be NULL; relu != 0 applies ReLU.
+ * ------------------------------------------------------------------------------------- */
+int dib_bias_act_nhwc(float *x_dev, const float *bias_dev, const float *residual_dev, long long n_elems,
+                      int C, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,3 +249,43 @@ def test_nms_sets_sorted_matches_per_set_nms(n):
     k2, c2 = ops.nms_sets_sorted(boxes.cuda(), None, 0.7)
     for b in range(B):
         assert k2[b, :int(c2[b])].cpu().tolist() == ops.nms(boxes[b].cuda(), fake.cuda(), 0.7).cpu().tolist()
+
+
+@pytest.mark.gpu
+def test_fused_conv_epilogue_matches_eager_ops():
+    """bias + residual + ReLU in one HIP pass (channels-last) against the eager torch ops, forward and
+    backward, through a whole ResNet-50 trunk; and the scalar (C % 4 != 0) kernel on its own."""
+    from detectinblur_amd.models import backbone as B
+    torch.manual_seed(0)
+    m = B.ResNet50Body().cuda().to(memory_format=torch.channels_last)
+    for mod in m.modules():
+        if isinstance(mod, B.FrozenBatchNorm2d):
+            mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-.2, .2); mod.running_mean.uniform_(-.2, .2); mod.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, 3, 96, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = {}
+    try:
+        for fuse in (True, False):
+            B.FUSE_EPILOGUE = fuse
+            for p in m.parameters():
+                p.grad = None
+            ys = m(x)
+            sum(y.square().mean() for y in ys).backward()
+            res[fuse] = ([y.detach().clone() for y in ys], m.layer2[0].conv1.weight.grad.clone(), m.conv1.weight.grad.clone())
+    finally:
+        B.FUSE_EPILOGUE = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+    for k in (1, 2):
+        assert torch.allclose(res[True][k], res[False][k], rtol=1e-4, atol=1e-5 * float(res[False][k].abs().max()))
+    # scalar kernel + bias gradient
+    t = torch.randn(2, 6, 5, 7, device="cuda").contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(6, device="cuda", requires_grad=True)
+    r = torch.randn_like(t)
+    a = (t.clone().requires_grad_(True), r.clone().requires_grad_(True))
+    y = B.bias_act(a[0] * 1.0, bias, a[1], relu=True)
+    y.sum().backward()
+    want = torch.relu(t + bias.detach().reshape(1, -1, 1, 1) + r)
+    assert torch.equal(y.detach(), want)
+    mask = (want > 0).float()
+    assert torch.equal(a[0].grad, mask) and torch.equal(a[1].grad, mask)
+    assert torch.allclose(bias.grad, mask.sum(dim=(0, 2, 3)))
