@@ -11,8 +11,9 @@ the keys it writes into `blur_dict`; what changes is where the time goes:
     does; the blur itself happens on the GPU in models/blur_functions.py;
   * `--cpu_blur` keeps the reference's FFT path (motion_blur/blur_image.py) for comparison runs.
 
-Extra, optional key (ignored by reference-shaped consumers): `blur_dict["psf_extent"]` =
-(rmin, rmax, cmin, cmax) of the PSF support, free to compute here and useful as a scheduling hint.
+Extra, optional keys (ignored by reference-shaped consumers): `blur_dict["psf_extent"]` =
+(rmin, rmax, cmin, cmax) of the PSF support and `blur_dict["psf_taps"]` = its non-zero count, free to
+compute here and used as scheduling hints by the GPU blur (heaviest image first).
 """
 import copy
 import math
@@ -249,6 +250,7 @@ class BlurImage(object):
         blur_dict["scale_factor_lambda1"] = s1
         blur_dict["scale_factor_lambda2"] = s2
         blur_dict["psf_extent"] = extent
+        blur_dict["psf_taps"] = int(np.count_nonzero(psf))
 
         if self.blur_type is not None:                                  # :418-428 nearest-type binning
             param_index = int(np.argmin(np.abs(np.asarray(PARAMS) - self.blur_type)))

@@ -15,7 +15,7 @@ for s, e, n in rows:
         agg[n][0] += 1; agg[n][1] += e - s; busy += e - s
 print("window %.1f ms, kernel-busy %.1f ms, %d launches" % (win_ms, busy / 1e6, sum(v[0] for v in agg.values())))
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
-    print("%6.2f%% %6d calls %9.1f us avg %9.2f ms  %s" % (100.0 * t / busy, c, t / c / 1e3, t / 1e6, n[:120]))
+    print("%6.2f%% %6d calls %9.1f us avg %9.2f ms  %s" % (100.0 * t / busy, c, t / c / 1e3, t / 1e6, n[:120] if "elementwise" not in n else n[:420]))
 
 # ---- idle gaps: where the GPU waits for the host ---------------------------------------------------
 win = [(s, e, n) for s, e, n in rows if s >= lo]

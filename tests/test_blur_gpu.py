@@ -179,6 +179,37 @@ def test_random_ragged_batch_vs_oracle():
     BF.blur_image_list(got, dicts, [_dev(p) for p in psfs])
     for g, w in zip(got, want):
         assert np.array_equal(_bits(g.cpu().numpy()), _bits(w))
+    # the optional scheduling hint reorders the launch, never the results
+    hinted = [dict(d, psf_taps=int(np.count_nonzero(p))) for d, p in zip(dicts, psfs)]
+    got = [_dev(a) for a in imgs]
+    BF.blur_image_list(got, hinted, [_dev(p) for p in psfs])
+    for g, w in zip(got, want):
+        assert np.array_equal(_bits(g.cpu().numpy()), _bits(w))
+
+
+def test_batch_larger_than_one_launch_chunk_and_skipped_entries():
+    """70 ragged images in one blur_image_list call (the device descriptor holds 32 images per launch:
+    three launches), every third one not blurred, PSFs of several extents; bit-exact vs the oracle."""
+    from detectinblur_amd.models import blur_functions as BF
+    rs = np.random.RandomState(77)
+    imgs, dicts, psfs = [], [], []
+    for i in range(70):
+        C = (1, 2, 3)[i % 3]
+        imgs.append(rs.random_sample((C, 65 + (i * 7) % 40, 66 + (i * 13) % 90)).astype(np.float16))
+        a = np.zeros((128, 128), np.float64)
+        n, sp = 3 + i % 9, 1 + (i * 5) % 40
+        a[np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127), np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127)] = rs.random_sample(n) + 0.05
+        psfs.append(O.to_half_like_torch(a))
+        dicts.append({"blurring": i % 3 != 1})
+    want = [a.copy() for a in imgs]
+    O.blur_image_list(want, dicts, psfs)
+    got = [_dev(a) for a in imgs]
+    untouched = [g for g, d in zip(got, dicts) if not d["blurring"]]
+    BF.blur_image_list(got, dicts, [_dev(p) if d["blurring"] else torch.zeros(1, dtype=torch.float16, device="cuda")
+                                    for p, d in zip(psfs, dicts)])
+    assert all(any(g is u for u in untouched) for g, d in zip(got, dicts) if not d["blurring"])
+    for g, w in zip(got, want):
+        assert np.array_equal(_bits(g.cpu().numpy()), _bits(w))
 
 
 def test_linearity_property_full_size():
