@@ -39,6 +39,7 @@ def build_parser():
     p.add_argument("--gpu_blur", action="store_true")
     p.add_argument("--expand_target_boxes", action="store_true")
     p.add_argument("--use_custom_image_norm", action="store_true")
+    p.add_argument("--warp_in_model", action="store_true", help="Warp and dewarp images before and after backbone.")
     p.add_argument("--early_stop", type=int, default=None)
     p.add_argument("--world-size", default=1, type=int)
     p.add_argument("--dist-url", default="env://")
@@ -58,7 +59,8 @@ def main(args):
     synthetic = dict(num_images=args.synthetic_images, size=tuple(args.synthetic_size)) if args.synthetic else None
 
     def detector(path=None):
-        m = _load(fasterrcnn_resnet50_fpn(num_classes=91, pretrained=False, pretrained_backbone=False), path).to(device)
+        m = _load(fasterrcnn_resnet50_fpn(num_classes=91, pretrained=False, pretrained_backbone=False,
+                                          warp_internally=args.warp_in_model), path).to(device)
         return torch.nn.parallel.DistributedDataParallel(m, device_ids=[args.gpu] if device.type == "cuda" else None) if args.distributed else m
 
     ensemble, estimator, model = None, None, None

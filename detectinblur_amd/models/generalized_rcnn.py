@@ -1,7 +1,7 @@
 """`GeneralizedRCNN` with the reference's extended forward signature (reference
 models/generalized_rcnn.py:78): per-image normalisation statistics travel with the call
-(`newMeans` / `newSTDs`); `thetas / lambda1s / lambda2s / killWarp` belong to the "squint" warper
-(`--warp_in_model`), which is out of scope here and therefore only accepted, not used.
+(`newMeans` / `newSTDs`); `thetas / lambda1s / lambda2s / killWarp` drive the "squint" warper
+(`--warp_in_model`, models/warper.py; reference generalized_rcnn.py:131-141).
 """
 from collections import OrderedDict
 
@@ -12,10 +12,11 @@ from torch import nn
 class GeneralizedRCNN(nn.Module):
     def __init__(self, backbone, rpn, roi_heads, transform, warp_internally=False):
         super().__init__()
-        if warp_internally:
-            raise NotImplementedError("--warp_in_model (models/warper.py) is outside the built hot path (SURVEY.md 8f)")
         self.transform, self.backbone, self.rpn, self.roi_heads = transform, backbone, rpn, roi_heads
-        self.warp_internally = False
+        self.warp_internally = warp_internally
+        if warp_internally:
+            from .warper import Warper
+            self.warper = Warper()
 
     def forward(self, images, targets=None, thetas=None, lambda1s=None, lambda2s=None, killWarp=False, newMeans=None,
                 newSTDs=None):
@@ -38,7 +39,15 @@ class GeneralizedRCNN(nn.Module):
         if targets is not None:
             flags = [(t["boxes"][:, 2:] <= t["boxes"][:, :2]).any() for t in targets]
             degenerate = torch.stack(flags) if flags else None
-        features = self.backbone(images.tensors)
+        if self.warp_internally and not killWarp:
+            # squint: stretch along the blur axes, run the trunk, un-stretch every pyramid level
+            features = self.backbone(self.warper(images.tensors, thetas, lambda1s, lambda2s))
+            if isinstance(features, torch.Tensor):
+                features = OrderedDict([("0", features)])
+            for key, feature in features.items():
+                features[key] = self.warper(feature, thetas, 1 / lambda1s, 1 / lambda2s)
+        else:
+            features = self.backbone(images.tensors)
         if isinstance(features, torch.Tensor):
             features = OrderedDict([("0", features)])
         proposals, proposal_losses = self.rpn(images, features, targets)

@@ -93,6 +93,7 @@ def build_parser():
     p.add_argument("--noise_level", default=0.001, type=float)
     p.add_argument("--add_block", action="store_true")
     p.add_argument("--use_custom_image_norm", action="store_true")
+    p.add_argument("--warp_in_model", action="store_true", help="Warp and dewarp images before and after backbone.")
     p.add_argument("--world-size", default=1, type=int)
     p.add_argument("--dist-url", default="env://")
     return p
@@ -133,7 +134,8 @@ def main(args):
 
     print("Creating model")
     model = fasterrcnn_resnet50_fpn(num_classes=num_classes, pretrained=args.pretrained, pretrained_backbone=args.pretrained,
-                                    trainable_backbone_layers=args.trainable_backbone_blocks)
+                                    trainable_backbone_layers=args.trainable_backbone_blocks,
+                                    warp_internally=args.warp_in_model)
     model.to(device)
     model_without_ddp = model
     if args.distributed:

@@ -215,6 +215,25 @@ def gen_fft(ns, store):
     store["fft_out"] = np.array(h.pilImageResult)
 
 
+def warper_inputs():
+    g = torch.Generator().manual_seed(99)
+    x = torch.rand(3, 3, 40, 56, generator=g)
+    feat = torch.randn(3, 8, 10, 14, generator=g)
+    th = torch.tensor([0.3, -1.1, 2.4]).half()
+    l1 = torch.tensor([0.9, 0.8, 1.0]).half()
+    l2 = torch.tensor([1.0, 0.95, 0.72]).half()
+    return x, feat, th, l1, l2
+
+
+def gen_warper(ns, store):
+    """Reference models/warper.py on CPU: image warp and the inverse-scale feature warp."""
+    import importlib
+    w = importlib.import_module("models.warper").Warper()
+    x, feat, th, l1, l2 = warper_inputs()
+    store["warp_image"] = w(x, th, l1, l2).numpy()
+    store["warp_feature"] = w(feat, th, 1 / l1, 1 / l2).numpy()
+
+
 PSF_STORE_RUNS = {"w0_of1_n2": (0, 1, 2), "w1_of2_n4": (1, 2, 4)}   # name -> (worker_index, num_workers, total_num_psfs)
 
 
@@ -245,6 +264,12 @@ def gen_psf_store(ns, meta):
 def main():
     ns = ref_harness.load()
     os.makedirs(OUT, exist_ok=True)
+    if "--only-warper" in sys.argv:
+        store = {}
+        gen_warper(ns, store)
+        np.savez_compressed(os.path.join(OUT, "warper.npz"), **store)
+        print("warper", {k: v.shape for k, v in store.items()})
+        return
     if "--only-psf-store" in sys.argv:      # incremental: adds one key to the committed meta.json
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
@@ -256,7 +281,7 @@ def main():
     meta = {"numpy": np.__version__, "torch": torch.__version__}
     gen_psf_store(ns, meta)
     for name, fn in (("traj", gen_trajectories), ("psf", gen_psfs), ("boxes", gen_boxes),
-                     ("norm", gen_norm), ("fft", gen_fft)):
+                     ("norm", gen_norm), ("fft", gen_fft), ("warper", gen_warper)):
         store = {}
         fn(ns, store)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)

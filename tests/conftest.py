@@ -43,5 +43,6 @@ def golden():
         norm = np.load(os.path.join(d, "norm.npz"))
         fft = np.load(os.path.join(d, "fft.npz"))
         blurdict = np.load(os.path.join(d, "blurdict.npz"))
+        warper = np.load(os.path.join(d, "warper.npz"))
         meta = json.load(open(os.path.join(d, "meta.json")))
     return G
