@@ -98,4 +98,5 @@ def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None):
         perm.sort(key=lambda k: -int(blur_dicts[idx[k]]["psf_taps"]))
     outs = blur_ops.sparse_blur([images_GPU[idx[k]] for k in perm], perm, tables, acc_mode)
     for j, k in enumerate(perm):
-        images_GPU[idx[k]] = outs[j].squeeze()
+        o = outs[j]
+        images_GPU[idx[k]] = o.squeeze() if 1 in o.shape else o       # reference :69 squeezes every unit dim
