@@ -385,7 +385,10 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
 // (Measured alternatives, scratch/: a persistent kernel pulling tiles from an XCD-sharded atomic
 // queue was 30-60 % slower -- the returning atomics and the per-tile descriptor fetches sit on the
 // critical path of every tile, and static striding loses ~20 us to tap-count imbalance; 8-wave
-// workgroups double the wave launches, whose rate bounds this kernel at ~32 us for 28,800 waves.)
+// workgroups double the wave launches, whose rate bounds this kernel at ~32 us for 28,800 waves.
+// An L2 look-ahead -- every workgroup touching, one dword per 128-byte line, the window of the tile
+// 8..256 positions further down its XCD's list, with the tap loop no longer draining vmcnt -- made
+// the kernel 7 % SLOWER at every distance: the fill is not waiting on HBM latency.)
 template <int NW, int TPW, bool ACC32 = false>
 __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K,
                                                                      unsigned long long *dbg) {
