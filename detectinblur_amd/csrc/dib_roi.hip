@@ -102,6 +102,7 @@ struct RoiLevels {
   float *gfeat[4];
   int H[4], W[4];
   float scale[4];
+  int n;
 };
 constexpr int ROI_CCHUNK = 256;
 
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_kernel(RoiLevels L, co
   extern __shared__ float tile[];  // [nc][P*P]
   const int k = blockIdx.x, c0 = blockIdx.y * ROI_CCHUNK, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int PP = P * P, nc = min(ROI_CCHUNK, C - c0);
-  const int lv = level ? __builtin_amdgcn_readfirstlane(level[k]) : 0;
+  // clamped: a level computed from a NaN / inf box area (diverged training) must not index past the table
+  const int lv = level ? min(max(__builtin_amdgcn_readfirstlane(level[k]), 0), L.n - 1) : 0;
   const int H = L.H[lv], W = L.W[lv];
   const RoiGeom g = roi_geom(rois + (size_t)k * 5, L.scale[lv], P, sr, aligned);
   const float *base = L.feat[lv] + (size_t)g.b * H * W * C + c0;
@@ -169,7 +171,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc_kernel(RoiLevels L, co
   const float *src = gout + ((size_t)k * C + c0) * PP;
   for (int i = t; i < nc * PP; i += 256) tile[i] = src[i];
   __syncthreads();
-  const int lv = level ? __builtin_amdgcn_readfirstlane(level[k]) : 0;
+  // clamped: a level computed from a NaN / inf box area (diverged training) must not index past the table
+  const int lv = level ? min(max(__builtin_amdgcn_readfirstlane(level[k]), 0), L.n - 1) : 0;
   const int H = L.H[lv], W = L.W[lv];
   const RoiGeom g = roi_geom(rois + (size_t)k * 5, L.scale[lv], P, sr, aligned);
   float *base = L.gfeat[lv] + (size_t)g.b * H * W * C + c0;
@@ -340,6 +343,7 @@ static int fill_levels(RoiLevels &L, const void *const *ptrs, bool grads, const 
     L.gfeat[i] = grads ? (float *)const_cast<void *>(ptrs[j]) : nullptr;
     L.H[i] = H[j]; L.W[i] = W[j]; L.scale[i] = scale[j];
   }
+  L.n = n_levels;
   return DIB_OK;
 }
 

@@ -382,7 +382,10 @@ class MultiScaleRoIAlign(torch.nn.Module):
         lvl = torch.floor(4 + torch.log2(torch.sqrt(area) / 224) + 1e-6).clamp(min=k_min, max=k_max).long() - int(k_min)
         if len(feats) <= 4 and P <= 7 and all(_is_nhwc(f) for f in feats):
             # channels-last pyramid: every level in one launch, no per-level index_select / scatter / host sync
-            return _RoIAlignNHWC.apply(rois, lvl.to(torch.int32), scales, P, self.sampling_ratio, False, *feats)
+            # nan_to_num + clamp: boxes of a diverged step (NaN / inf area) must still name a real level
+            lvl = torch.nan_to_num(torch.floor(4 + torch.log2(torch.sqrt(area) / 224) + 1e-6), nan=k_min, posinf=k_max, neginf=k_min)
+            lvl = (lvl.clamp(min=k_min, max=k_max) - k_min).to(torch.int32)
+            return _RoIAlignNHWC.apply(rois, lvl, scales, P, self.sampling_ratio, False, *feats)
         out = torch.zeros((rois.shape[0], feats[0].shape[1], P, P), dtype=feats[0].dtype, device=rois.device)
         for i, (f, s) in enumerate(zip(feats, scales)):
             idx = torch.where(lvl == i)[0]

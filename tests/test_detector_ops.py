@@ -289,3 +289,24 @@ def test_fused_conv_epilogue_matches_eager_ops():
     mask = (want > 0).float()
     assert torch.equal(a[0].grad, mask) and torch.equal(a[1].grad, mask)
     assert torch.allclose(bias.grad, mask.sum(dim=(0, 2, 3)))
+
+
+@pytest.mark.gpu
+def test_non_finite_boxes_do_not_leave_the_feature_maps():
+    """A diverged step produces NaN / inf proposals; pooling and NMS must stay inside their buffers
+    (the level of such a box is clamped, its samples contribute nothing or garbage, never a fault)."""
+    rs = np.random.RandomState(2)
+    sizes = [(64, 96), (32, 48), (16, 24), (8, 12)]
+    feats = OrderedDict((str(i), torch.tensor(rs.randn(1, 16, h, w), dtype=torch.float32).cuda()
+                         .contiguous(memory_format=torch.channels_last).requires_grad_(True)) for i, (h, w) in enumerate(sizes))
+    nan, inf = float("nan"), float("inf")
+    boxes = [torch.tensor([[10.0, 10, 60, 70], [nan, nan, nan, nan], [0, 0, inf, inf], [-inf, 5, 40, nan], [1e30, 1e30, 2e30, 2e30],
+                           [5, 5, 5, 5]], dtype=torch.float32).cuda()]
+    pool = ops.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    out = pool(feats, boxes, [(256, 384)])
+    out[0].sum().backward()                       # finite RoI: finite gradient path
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[0]).all()
+    keep, count = ops.nms_sets_sorted(boxes[0][None], None, 0.5)
+    torch.cuda.synchronize()
+    assert 1 <= int(count[0]) <= 6
