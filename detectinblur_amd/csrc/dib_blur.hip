@@ -60,26 +60,30 @@ typedef unsigned long long u2;
 //             8 x ds_read_b64 -> other buf  next tap's data (address = its ltap offset + lane base)
 //             s_load_dword                  ltap word of the tap after next
 //             16 x v_pk_mul_f16, 16 x v_pk_add_f16 on this tap's data while all of that is in flight
-// ~10 scalar + 1 vector instruction of overhead per 32 packed operations.
+// 7 scalar + 1 vector instruction of overhead per 32 packed operations.  Scalar instructions matter
+// here: with one or two waves per SIMD in their tap loops (the usual case, the others are filling or
+// storing) a wave's own SALU work is on its critical path, it is not hidden behind another wave's
+// VALU.  Hence: the weight is read straight from the high half of the ltap SGPR (op_sel, no
+// shift + pack), the LDS address is one v_mad_u32_u16 (no scalar mask), the loop ends on the borrow
+// of the counter's decrement, and the last tap does not branch around its (harmless, zero-padded)
+// look-ahead -- 13 -> 7 scalar instructions per tap, -2.5 % kernel time, bit-identical results.
 // ltap word = byte offset of the tap's source word in the window (low 16) | fp16 weight (high 16).
 // Operands: %0-%15 accumulators, %16 byte offset of the next ltap, %17 taps left, %18 A (tap being
 // multiplied), %19 B (tap being fetched), %20 C (tap in flight), %21 scalar temp, %22 ltaps, %23 lane base.
-#define DIB_MUL(b, i) "v_pk_mul_f16 v" #b ", %21, v" #b "\n\t"
+#define DIB_MUL(b, i) "v_pk_mul_f16 v" #b ", %18, v" #b " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
 #define DIB_ADD(b, i) "v_pk_add_f16 %" #i ", %" #i ", v" #b "\n\t"
 #define DIB_MADD_A                                                                                          \
-  "s_lshr_b32 %21, %18, 16\n\ts_pack_ll_b32_b16 %21, %21, %21\n\t"                                            \
   DIB_MUL(64, 0) DIB_MUL(65, 1) DIB_MUL(66, 2) DIB_MUL(67, 3) DIB_MUL(68, 4) DIB_MUL(69, 5) DIB_MUL(70, 6) DIB_MUL(71, 7) \
   DIB_MUL(72, 8) DIB_MUL(73, 9) DIB_MUL(74, 10) DIB_MUL(75, 11) DIB_MUL(76, 12) DIB_MUL(77, 13) DIB_MUL(78, 14) DIB_MUL(79, 15) \
   DIB_ADD(64, 0) DIB_ADD(65, 1) DIB_ADD(66, 2) DIB_ADD(67, 3) DIB_ADD(68, 4) DIB_ADD(69, 5) DIB_ADD(70, 6) DIB_ADD(71, 7) \
   DIB_ADD(72, 8) DIB_ADD(73, 9) DIB_ADD(74, 10) DIB_ADD(75, 11) DIB_ADD(76, 12) DIB_ADD(77, 13) DIB_ADD(78, 14) DIB_ADD(79, 15)
 #define DIB_MADD_B                                                                                          \
-  "s_lshr_b32 %21, %18, 16\n\ts_pack_ll_b32_b16 %21, %21, %21\n\t"                                            \
   DIB_MUL(80, 0) DIB_MUL(81, 1) DIB_MUL(82, 2) DIB_MUL(83, 3) DIB_MUL(84, 4) DIB_MUL(85, 5) DIB_MUL(86, 6) DIB_MUL(87, 7) \
   DIB_MUL(88, 8) DIB_MUL(89, 9) DIB_MUL(90, 10) DIB_MUL(91, 11) DIB_MUL(92, 12) DIB_MUL(93, 13) DIB_MUL(94, 14) DIB_MUL(95, 15) \
   DIB_ADD(80, 0) DIB_ADD(81, 1) DIB_ADD(82, 2) DIB_ADD(83, 3) DIB_ADD(84, 4) DIB_ADD(85, 5) DIB_ADD(86, 6) DIB_ADD(87, 7) \
   DIB_ADD(88, 8) DIB_ADD(89, 9) DIB_ADD(90, 10) DIB_ADD(91, 11) DIB_ADD(92, 12) DIB_ADD(93, 13) DIB_ADD(94, 14) DIB_ADD(95, 15)
 #define DIB_READ8(base)                                                                                      \
-  "s_and_b32 %21, %19, 0xffff\n\tv_add_u32 v96, %21, %23\n\t"                                                 \
+  "v_mad_u32_u16 v96, %19, 1, %23\n\t"                                                                       \
   "ds_read_b64 v[" #base ":" #base "+1], v96\n\tds_read_b64 v[" #base "+2:" #base "+3], v96 offset:768\n\t"   \
   "ds_read_b64 v[" #base "+4:" #base "+5], v96 offset:1536\n\tds_read_b64 v[" #base "+6:" #base "+7], v96 offset:2304\n\t" \
   "ds_read_b64 v[" #base "+8:" #base "+9], v96 offset:3072\n\tds_read_b64 v[" #base "+10:" #base "+11], v96 offset:3840\n\t" \
@@ -88,7 +92,8 @@ typedef unsigned long long u2;
 
 // acc[i][0] / acc[i][1] (i = 0..7): the packed fp16 accumulators of this lane's 8 rows x 4 columns
 __device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
-  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n);
+  // cnt = taps left minus one: the borrow of its decrement ends the loop (n >= 1 in every segment)
+  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
   unsigned sA, sB, sC, st;
   unsigned a[16];
 #pragma unroll
@@ -103,18 +108,14 @@ __device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long 
       "Ldib_loop%=:\n\t"
       // ---- tap in buffer A ----
       "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t"
-      "s_cmp_eq_u32 %17, 1\n\ts_cbranch_scc1 Ldib_lastA%=\n\t"
       DIB_READ8(80) DIB_NEXTTAP
-      "Ldib_lastA%=:\n\t"
       DIB_MADD_A
-      "s_sub_u32 %17, %17, 1\n\ts_cmp_eq_u32 %17, 0\n\ts_cbranch_scc1 Ldib_done%=\n\t"
+      "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc1 Ldib_done%=\n\t"
       // ---- tap in buffer B ----
       "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t"
-      "s_cmp_eq_u32 %17, 1\n\ts_cbranch_scc1 Ldib_lastB%=\n\t"
       DIB_READ8(64) DIB_NEXTTAP
-      "Ldib_lastB%=:\n\t"
       DIB_MADD_B
-      "s_sub_u32 %17, %17, 1\n\ts_cmp_eq_u32 %17, 0\n\ts_cbranch_scc0 Ldib_loop%=\n\t"
+      "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc0 Ldib_loop%=\n\t"
       "Ldib_done%=:\n\t"
       "s_waitcnt lgkmcnt(0)"
       : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]),
