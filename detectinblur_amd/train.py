@@ -154,10 +154,12 @@ def main(args):
     elif args.start_from_weights:                                       # :260-263
         model_without_ddp.load_state_dict(torch.load(args.start_from_weights, map_location="cpu", weights_only=False)["model"])
 
-    eval_kw = dict(device=device, distributed_mode=args.distributed, early_stop=args.early_stop,
-                   use_custom_image_norm=args.use_custom_image_norm)
+    # the clean pass never uses the custom statistics (reference train.py:346-349 passes none of the blur
+    # options): its blur_dicts have no "blurring" key for get_norm_params to read
+    clean_kw = dict(device=device, distributed_mode=args.distributed, early_stop=args.early_stop)
+    eval_kw = dict(clean_kw, use_custom_image_norm=args.use_custom_image_norm)
     if args.eval_first:
-        evaluate(model, data_loader_test, vanilla_eval=True, **eval_kw)
+        evaluate(model, data_loader_test, vanilla_eval=True, **clean_kw)
 
     print("Start training")
     start = time.time()
@@ -173,7 +175,7 @@ def main(args):
             utils.save_on_master({"model": model_without_ddp.state_dict(), "optimizer": optimizer.state_dict(),
                                   "lr_scheduler": lr_scheduler.state_dict(), "args": args, "epoch": epoch},
                                  os.path.join(args.output_dir, "model_{}.pth".format(epoch)))
-        evaluate(model, data_loader_test, vanilla_eval=True, **eval_kw)
+        evaluate(model, data_loader_test, vanilla_eval=True, **clean_kw)
         evaluate(model, data_loader_test_blur, blurring_images=True, gpu_blur=args.gpu_blur,
                  expand_target_boxes=args.expand_target_boxes, **eval_kw)
     print("Training time {}".format(str(datetime.timedelta(seconds=int(time.time() - start)))))

@@ -67,3 +67,32 @@ def test_ensemble_routing_runs():
     out = evaluate(None, _loader(False, 2), torch.device("cuda"), blurring_images=True, gpu_blur=True, expand_target_boxes=True,
                    use_ensemble=True, ensemble_models=nets, blur_estimator=est, LEHE=True)
     assert len(out["routes"]) == 2 and all(r in (0, 1, 2, 3) for r in out["routes"])
+
+
+def test_train_cli_with_stored_psfs_end_to_end(tmp_path, capsys):
+    """BASELINE configs[3] in miniature: `train.py --blur_train --gpu_blur --use_stored_psfs` on a store
+    written by the store builder (2 PSFs per directory), two iterations, finite losses, checkpoint saved."""
+    from detectinblur_amd import train
+    from detectinblur_amd.dataset_utils import generate_PSFs as G
+    dest = str(tmp_path) + "/"
+    G.main(G.get_parser().parse_args(["--destination_path", dest, "--num_workers", "1", "--total_num_psfs", "2", "--packed"]))
+    out = str(tmp_path / "run")
+    args = train.build_parser().parse_args([
+        "--synthetic", "--synthetic_images", "4", "--synthetic_size", "160", "224", "--blur_train", "--gpu_blur",
+        "--use_stored_psfs", "--stored_psf_directory", dest + "psfs", "--stored_psf_count", "2", "--param_index", "1",
+        "--low_exposure", "--expand_target_boxes", "--use_custom_image_norm", "-b", "2", "--epochs", "1", "--early_stop", "2",
+        "--lr", "0.002", "--print_freq", "1", "--output_dir", out])
+    train.main(args)
+    text = capsys.readouterr().out
+    assert "loss_classifier" in text and "nan" not in text.lower().split("namespace")[-1]
+
+
+def test_evaluate_cli_ensemble_sweep_end_to_end(capsys):
+    """BASELINE configs[4] in miniature: the (type x exposure) sweep through 4 detectors + estimator."""
+    from detectinblur_amd import evaluate as E
+    args = E.build_parser().parse_args(["--synthetic", "--synthetic_images", "2", "--synthetic_size", "160", "224", "--use_ensemble",
+                                      "--LEHE", "--use_blur_estimator", "--blur_eval", "--gpu_blur", "--expand_target_boxes",
+                                      "--early_stop", "1"])
+    E.main(args)
+    text = capsys.readouterr().out
+    assert text.count("routes") == 15           # 3 blur types x 5 exposures
