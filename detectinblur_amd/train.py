@@ -139,7 +139,10 @@ def main(args):
     model.to(device)
     model_without_ddp = model
     if args.distributed:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.gpu] if device.type == "cuda" else None)
+        # the buffers are frozen batch-norm statistics: equal on all ranks after DDP's construction-time sync,
+        # so the per-forward re-broadcast (~7 ms per step) is switched off
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.gpu] if device.type == "cuda" else None,
+                                                          broadcast_buffers=False, gradient_as_bucket_view=True)
         model_without_ddp = model.module
     params = [p for p in model.parameters() if p.requires_grad]
     optimizer = torch.optim.SGD(params, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
