@@ -61,7 +61,10 @@ def main(args):
     def detector(path=None):
         m = _load(fasterrcnn_resnet50_fpn(num_classes=91, pretrained=False, pretrained_backbone=False,
                                           warp_internally=args.warp_in_model), path).to(device)
-        return torch.nn.parallel.DistributedDataParallel(m, device_ids=[args.gpu] if device.type == "cuda" else None) if args.distributed else m
+        if not args.distributed:
+            return m
+        return torch.nn.parallel.DistributedDataParallel(m, device_ids=[args.gpu] if device.type == "cuda" else None,
+                                                         broadcast_buffers=False)
 
     ensemble, estimator, model = None, None, None
     if args.use_ensemble:                                               # reference evaluate.py:159-205
