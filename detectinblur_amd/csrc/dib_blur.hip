@@ -205,8 +205,9 @@ template <int R>
 __device__ __forceinline__ void tap_loop_fp32(float (&acc)[R][4], const unsigned *__restrict__ ltaps, int t0, int n,
                                               unsigned lane_addr) {
 #pragma clang fp contract(off)
+#pragma unroll 2
   for (int t = t0; t < t0 + n; ++t) {
-    const unsigned lt = __builtin_amdgcn_readfirstlane(ltaps[t]);
+    const unsigned lt = ltaps[t];
     const float w = (float)__builtin_bit_cast(_Float16, (unsigned short)(lt >> 16));
     const unsigned a = lane_addr + (lt & 0xffffu);
 #pragma unroll
@@ -217,8 +218,10 @@ __device__ __forceinline__ void tap_loop_fp32(float (&acc)[R][4], const unsigned
       const float p1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.x >> 16));
       const float p2 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.y & 0xffffu));
       const float p3 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.y >> 16));
-      acc[i][0] = acc[i][0] + p0 * w; acc[i][1] = acc[i][1] + p1 * w;
-      acc[i][2] = acc[i][2] + p2 * w; acc[i][3] = acc[i][3] + p3 * w;
+      // explicit fma: the product is exact in fp32, so fused == unfused bit for bit, and hipcc can fold
+      // the fp16 -> fp32 conversions of both factors into v_fma_mix_f32
+      acc[i][0] = __builtin_fmaf(p0, w, acc[i][0]); acc[i][1] = __builtin_fmaf(p1, w, acc[i][1]);
+      acc[i][2] = __builtin_fmaf(p2, w, acc[i][2]); acc[i][3] = __builtin_fmaf(p3, w, acc[i][3]);
     }
   }
 }
@@ -336,7 +339,9 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
     if (sg == 0) stamp(dbg, 1);
 
     // ---- accumulate: taps of the segment in row-major order (hand-written loop above) -----------------
-    if constexpr (ACC32) tap_loop_fp32<R>(acc32, reinterpret_cast<const unsigned *>(ltaps), t0, n, lane_addr);
+    // the table pointer itself (kernel-argument derived, provably uniform): hipcc then fetches the ltap words
+    // with scalar loads; a pointer rebuilt from an integer would go through per-lane flat loads
+    if constexpr (ACC32) tap_loop_fp32<R>(acc32, reinterpret_cast<const unsigned *>(tab + table_ltaps_off(K)), t0, n, lane_addr);
     else if constexpr (R == 8) tap_loop_r8(acc, ltaps, t0, n, lane_addr);
     else tap_loop_r4(acc, ltaps, t0, n, lane_addr);
     if (sg == 0) stamp(dbg, 2);
