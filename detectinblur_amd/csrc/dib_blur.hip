@@ -67,6 +67,10 @@ typedef unsigned long long u2;
 // shift + pack), the LDS address is one v_mad_u32_u16 (no scalar mask), the loop ends on the borrow
 // of the counter's decrement, and the last tap does not branch around its (harmless, zero-padded)
 // look-ahead -- 13 -> 7 scalar instructions per tap, -2.5 % kernel time, bit-identical results.
+// (Also built and measured: a x3-unrolled loop with THREE data buffers -- LDS look-ahead of two taps,
+// `s_waitcnt lgkmcnt(8)` -- that takes its ltap words from a VGPR with v_readlane, 4 scalar instructions
+// per tap and no scalar-memory loads at all.  Bit-identical, but 3 % slower: LDS latency is already
+// covered by one tap of look-ahead, and the readlane -> address -> ds_read chain opens every tap.)
 // ltap word = byte offset of the tap's source word in the window (low 16) | fp16 weight (high 16).
 // Operands: %0-%15 accumulators, %16 byte offset of the next ltap, %17 taps left, %18 A (tap being
 // multiplied), %19 B (tap being fetched), %20 C (tap in flight), %21 scalar temp, %22 ltaps, %23 lane base.
