@@ -1,0 +1,88 @@
+"""Randomised parity sweep of the HIP blur against the oracle: random image shapes (all three padding
+regimes), channel counts, PSF canvases, tap counts / extents / weight magnitudes, batch compositions.
+Seeded; DIB_FUZZ_CASES=<n> widens it (the default keeps the suite fast)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dib_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rs):
+    K = 256 if rs.random_sample() < 0.15 else 128
+    regime = rs.randint(0, 3)
+    if K == 128 and regime == 0:      # zero padding: one side below 64
+        H, W = (rs.randint(1, 64), rs.randint(1, 300)) if rs.random_sample() < 0.5 else (rs.randint(1, 200), rs.randint(1, 64))
+    else:                             # reflect (> 64 both) or replicate (any size, 256 canvas)
+        lo = 65 if K == 128 else 1
+        H, W = rs.randint(lo, 260), rs.randint(lo, 700)
+    C = rs.randint(1, 4)
+    img = (rs.random_sample((C, H, W)) * rs.choice([1.0, 1.0, 255.0, 1e-3])).astype(np.float16)
+    a = np.zeros((K, K), np.float64)
+    n = rs.randint(1, 60)
+    spread = rs.choice([1, 3, 8, 20, 40, K // 2 - 1])
+    rr = np.clip(rs.randint(-spread, spread + 1, n) + K // 2 - 1, 0, K - 1)
+    cc = np.clip(rs.randint(-spread, spread + 1, n) + K // 2 - 1, 0, K - 1)
+    a[rr, cc] = rs.random_sample(n) + 0.01
+    if rs.random_sample() < 0.2:
+        a[rs.randint(0, K), rs.randint(0, K)] = 0.5      # a stray far tap: extra segments
+    return img, O.to_half_like_torch(a * rs.choice([1.0, 0.37, 3.0]))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DIB_FUZZ_BATCHES", "6"))))
+def test_random_batches_bit_exact(seed):
+    from detectinblur_amd.models import blur_functions as BF
+    rs = np.random.RandomState(1000 + seed)
+    per_batch = int(os.environ.get("DIB_FUZZ_CASES", "10"))
+    cases = [_case(rs) for _ in range(per_batch)]
+    for K in (128, 256):
+        sub = [(i, p) for i, p in cases if p.shape[0] == K]
+        if not sub:
+            continue
+        imgs = [i for i, _ in sub]
+        psfs = [p for _, p in sub]
+        dicts = [{"blurring": rs.random_sample() < 0.85} for _ in sub]
+        want = [a.copy() for a in imgs]
+        O.blur_image_list(want, dicts, psfs)
+        got = [torch.from_numpy(a).cuda() for a in imgs]
+        BF.blur_image_list(got, dicts, [torch.from_numpy(p).cuda() for p in psfs])
+        for k, (g, w) in enumerate(zip(got, want)):
+            # blurred entries come back squeezed (reference :69), skipped ones are the caller's own tensors
+            assert g.shape == w.shape, (seed, K, k, imgs[k].shape, dicts[k])
+            assert np.array_equal(g.cpu().numpy().view(np.uint16), w.view(np.uint16)), (seed, K, k, imgs[k].shape)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_random_images_fp32_accumulate_bit_exact(seed):
+    """The same random population through DIB_ACC_FP32, against the oracle's restatement of that mode."""
+    from detectinblur_amd import _lib
+    from detectinblur_amd.models import blur_functions as BF
+    rs = np.random.RandomState(5000 + seed)
+    for _ in range(int(os.environ.get("DIB_FUZZ_CASES", "10"))):
+        img, psf = _case(rs)
+        pn = O.normalize_psf(psf)
+        want = O.manual_blur(img, pn, fp32_accumulate=True)
+        got = BF.manual_blur(torch.from_numpy(img).cuda(), torch.from_numpy(pn).cuda(), acc_mode=_lib.DIB_ACC_FP32).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint16), want.view(np.uint16)), (seed, img.shape)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_random_boxes_expand_and_clamp(seed):
+    """expand_targets on random boxes / PSF extents / image sizes against the oracle."""
+    from detectinblur_amd import utils
+    rs = np.random.RandomState(7000 + seed)
+    for _ in range(20):
+        img, psf = _case(rs)
+        if psf.shape[0] != 128:
+            continue
+        C, H, W = img.shape
+        n = rs.randint(0, 12)
+        b = rs.uniform(-20, max(H, W) + 20, (n, 4)).astype(np.float32)
+        want = O.expand_boxes(b.copy(), psf, H, W) if n else b
+        t = [{"boxes": torch.from_numpy(b.copy()).cuda()}]
+        utils.expand_targets(t, [{"blurring": True}], [torch.from_numpy(psf).cuda()], [torch.from_numpy(img).cuda()])
+        assert np.array_equal(t[0]["boxes"].cpu().numpy(), want)
