@@ -86,3 +86,27 @@ def test_random_boxes_expand_and_clamp(seed):
         t = [{"boxes": torch.from_numpy(b.copy()).cuda()}]
         utils.expand_targets(t, [{"blurring": True}], [torch.from_numpy(psf).cuda()], [torch.from_numpy(img).cuda()])
         assert np.array_equal(t[0]["boxes"].cpu().numpy(), want)
+
+
+def test_random_trajectories_rasterise_bit_exact_on_device():
+    """HIP rasteriser + centring + crop + Half conversion against the native host classes (themselves
+    pinned to the reference's goldens) for random blur types and exposure fractions."""
+    from detectinblur_amd import blur_ops
+    from detectinblur_amd.motion_blur.generate_PSF import PSF
+    from detectinblur_amd.motion_blur.generate_trajectory import Trajectory
+    rs = np.random.RandomState(31)
+    np.random.seed(4321)
+    trajs, fracs, want64, want16 = [], [], [], []
+    for _ in range(24):
+        expl = float(rs.choice([0.005, 0.001, 0.00005, 0.01]))
+        frac = float(rs.choice([1 / 25, 1 / 18, 1 / 10, 1 / 5, 1 / 2, 1, rs.uniform(0.02, 1.0)]))
+        tr = Trajectory(canvas=256, max_len=96, expl=expl).fit()
+        p = PSF(canvas=256, trajectory=tr, fraction=[frac])
+        p.fit()
+        p.centerPSF()
+        crop = np.ascontiguousarray(p.PSFs[0][64:192, 64:192])
+        trajs.append(np.asarray(tr.x, dtype=np.complex128)); fracs.append(frac)
+        want64.append(crop); want16.append(O.to_half_like_torch(crop))
+    p64, p16 = blur_ops.rasterize_psfs(torch.from_numpy(np.stack(trajs)), fracs, canvas=256, center=True)
+    assert np.array_equal(p64.cpu().numpy().view(np.uint64), np.stack(want64).view(np.uint64))
+    assert np.array_equal(p16.cpu().numpy().view(np.uint16), np.stack(want16).view(np.uint16))
