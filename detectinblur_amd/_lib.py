@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 
 DIB_F16, DIB_F32 = 0, 1
-DIB_ACC_BITEXACT, DIB_ACC_FP32 = 0, 1
+DIB_ACC_BITEXACT, DIB_ACC_FP32, DIB_ACC_FMA16 = 0, 1, 2
 DIB_EINVAL, DIB_ESHAPE, DIB_EHIP, DIB_ENOT128 = -1, -2, -3, -4
 
 _lib = None

@@ -86,6 +86,15 @@ typedef unsigned long long u2;
   DIB_MUL(88, 8) DIB_MUL(89, 9) DIB_MUL(90, 10) DIB_MUL(91, 11) DIB_MUL(92, 12) DIB_MUL(93, 13) DIB_MUL(94, 14) DIB_MUL(95, 15) \
   DIB_ADD(80, 0) DIB_ADD(81, 1) DIB_ADD(82, 2) DIB_ADD(83, 3) DIB_ADD(84, 4) DIB_ADD(85, 5) DIB_ADD(86, 6) DIB_ADD(87, 7) \
   DIB_ADD(88, 8) DIB_ADD(89, 9) DIB_ADD(90, 10) DIB_ADD(91, 11) DIB_ADD(92, 12) DIB_ADD(93, 13) DIB_ADD(94, 14) DIB_ADD(95, 15)
+// DIB_ACC_FMA16: the same loop with ONE packed fused multiply-add per register (one rounding per tap
+// instead of two): half the tap arithmetic, not the reference's arithmetic.
+#define DIB_FMA(b, i) "v_pk_fma_f16 %" #i ", %18, v" #b ", %" #i " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define DIB_FMADD_A                                                                                         \
+  DIB_FMA(64, 0) DIB_FMA(65, 1) DIB_FMA(66, 2) DIB_FMA(67, 3) DIB_FMA(68, 4) DIB_FMA(69, 5) DIB_FMA(70, 6) DIB_FMA(71, 7) \
+  DIB_FMA(72, 8) DIB_FMA(73, 9) DIB_FMA(74, 10) DIB_FMA(75, 11) DIB_FMA(76, 12) DIB_FMA(77, 13) DIB_FMA(78, 14) DIB_FMA(79, 15)
+#define DIB_FMADD_B                                                                                         \
+  DIB_FMA(80, 0) DIB_FMA(81, 1) DIB_FMA(82, 2) DIB_FMA(83, 3) DIB_FMA(84, 4) DIB_FMA(85, 5) DIB_FMA(86, 6) DIB_FMA(87, 7) \
+  DIB_FMA(88, 8) DIB_FMA(89, 9) DIB_FMA(90, 10) DIB_FMA(91, 11) DIB_FMA(92, 12) DIB_FMA(93, 13) DIB_FMA(94, 14) DIB_FMA(95, 15)
 #define DIB_READ8(base)                                                                                      \
   "v_mad_u32_u16 v96, %19, 1, %23\n\t"                                                                       \
   "ds_read_b64 v[" #base ":" #base "+1], v96\n\tds_read_b64 v[" #base "+2:" #base "+3], v96 offset:768\n\t"   \
@@ -95,6 +104,7 @@ typedef unsigned long long u2;
 #define DIB_NEXTTAP "s_load_dword %20, %22, %16\n\ts_add_u32 %16, %16, 4\n\t"
 
 // acc[i][0] / acc[i][1] (i = 0..7): the packed fp16 accumulators of this lane's 8 rows x 4 columns
+template <bool FUSED>
 __device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
   // cnt = taps left minus one: the borrow of its decrement ends the loop (n >= 1 in every segment)
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
@@ -102,33 +112,36 @@ __device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long 
   unsigned a[16];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { a[2 * i] = __builtin_bit_cast(unsigned, acc[i][0]); a[2 * i + 1] = __builtin_bit_cast(unsigned, acc[i][1]); }
-  asm volatile(
-      // vmcnt(0): window loads whose values were never used (rows past the window's end) may still be
-      // in flight, and hipcc is free to have put their destinations into the registers clobbered
-      // here -- it waits before ITS OWN next write to such a register, but not before this asm's.
-      // prologue: ltap[t0] -> B, ltap[t0+1] -> C, data of tap t0 -> buffer A
-      "s_load_dword %19, %22, %16\n\ts_add_u32 %16, %16, 4\n\t" DIB_NEXTTAP
-      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIB_READ8(64)
-      "Ldib_loop%=:\n\t"
-      // ---- tap in buffer A ----
-      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t"
-      DIB_READ8(80) DIB_NEXTTAP
-      DIB_MADD_A
-      "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc1 Ldib_done%=\n\t"
-      // ---- tap in buffer B ----
-      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t"
-      DIB_READ8(64) DIB_NEXTTAP
-      DIB_MADD_B
-      "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc0 Ldib_loop%=\n\t"
-      "Ldib_done%=:\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]),
-        "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+s"(toff), "+s"(cnt), "=&s"(sA), "=&s"(sB),
-        "=&s"(sC), "=&s"(st)
-      : "s"(ltaps), "v"(lane_addr)
-      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80",
-        "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "scc",
-        "memory");
+#define DIB_R8_ASM(ARITH_A, ARITH_B) \
+  asm volatile( \
+      /* vmcnt(0): window loads whose values were never used (rows past the window's end) may still be */ \
+      /* in flight, and hipcc is free to have put their destinations into the registers clobbered */ \
+      /* here -- it waits before ITS OWN next write to such a register, but not before this asm's. */ \
+      /* prologue: ltap[t0] -> B, ltap[t0+1] -> C, data of tap t0 -> buffer A */ \
+      "s_load_dword %19, %22, %16\n\ts_add_u32 %16, %16, 4\n\t" DIB_NEXTTAP \
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIB_READ8(64) \
+      "Ldib_loop%=:\n\t" \
+      /* ---- tap in buffer A ---- */ \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t" \
+      DIB_READ8(80) DIB_NEXTTAP \
+      ARITH_A \
+      "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc1 Ldib_done%=\n\t" \
+      /* ---- tap in buffer B ---- */ \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t" \
+      DIB_READ8(64) DIB_NEXTTAP \
+      ARITH_B \
+      "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc0 Ldib_loop%=\n\t" \
+      "Ldib_done%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)" \
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), \
+        "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+s"(toff), "+s"(cnt), "=&s"(sA), "=&s"(sB), \
+        "=&s"(sC), "=&s"(st) \
+      : "s"(ltaps), "v"(lane_addr) \
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", \
+        "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "scc", \
+        "memory")
+  if constexpr (FUSED) { DIB_R8_ASM(DIB_FMADD_A, DIB_FMADD_B); } else { DIB_R8_ASM(DIB_MADD_A, DIB_MADD_B); }
+#undef DIB_R8_ASM
 #pragma unroll
   for (int i = 0; i < 8; ++i) { acc[i][0] = __builtin_bit_cast(h2, a[2 * i]); acc[i][1] = __builtin_bit_cast(h2, a[2 * i + 1]); }
 }
@@ -136,6 +149,9 @@ __device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long 
 #undef DIB_ADD
 #undef DIB_MADD_A
 #undef DIB_MADD_B
+#undef DIB_FMA
+#undef DIB_FMADD_A
+#undef DIB_FMADD_B
 #undef DIB_READ8
 #undef DIB_NEXTTAP
 
@@ -245,7 +261,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *img_bas
 }
 
 // One workgroup = one (image, channel, 256 x 32 tile).  NW waves, R = 32 / NW rows per lane.
-template <int NW, bool ZERO, bool ACC32>
+template <int NW, bool ZERO, int ACC>
 __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx,
                                               int ty, uint2 *lds, unsigned long long *dbg) {
 #pragma clang fp contract(off)
@@ -345,8 +361,8 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
     // ---- accumulate: taps of the segment in row-major order (hand-written loop above) -----------------
     // the table pointer itself (kernel-argument derived, provably uniform): hipcc then fetches the ltap words
     // with scalar loads; a pointer rebuilt from an integer would go through per-lane flat loads
-    if constexpr (ACC32) tap_loop_fp32<R>(acc32, reinterpret_cast<const unsigned *>(tab + table_ltaps_off(K)), t0, n, lane_addr);
-    else if constexpr (R == 8) tap_loop_r8(acc, ltaps, t0, n, lane_addr);
+    if constexpr (ACC == DIB_ACC_FP32) tap_loop_fp32<R>(acc32, reinterpret_cast<const unsigned *>(tab + table_ltaps_off(K)), t0, n, lane_addr);
+    else if constexpr (R == 8) tap_loop_r8<ACC == DIB_ACC_FMA16>(acc, ltaps, t0, n, lane_addr);
     else tap_loop_r4(acc, ltaps, t0, n, lane_addr);
     if (sg == 0) stamp(dbg, 2);
   }
@@ -364,7 +380,7 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
         // halves are extracted with integer ops: hipcc (ROCm 7.2) stored the LOW half twice when the
         // high element of the fp16x2 accumulator was taken with a vector subscript
         unsigned a = __builtin_bit_cast(unsigned, acc[i][0]), b = __builtin_bit_cast(unsigned, acc[i][1]);
-        if constexpr (ACC32) {
+        if constexpr (ACC == DIB_ACC_FP32) {
           a = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][0]) |
               ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][1]) << 16);
           b = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][2]) |
@@ -399,7 +415,7 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
 // An L2 look-ahead -- every workgroup touching, one dword per 128-byte line, the window of the tile
 // 8..256 positions further down its XCD's list, with the tap loop no longer draining vmcnt -- made
 // the kernel 7 % SLOWER at every distance: the fill is not waiting on HBM latency.)
-template <int NW, int TPW, bool ACC32 = false>
+template <int NW, int TPW, int ACC = DIB_ACC_BITEXACT>
 __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K,
                                                                      unsigned long long *dbg) {
   extern __shared__ uint2 lds[];
@@ -440,8 +456,8 @@ __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch b
     const int ty = sy * TPW + rep;
     if (ty * TH >= d.H) break;
     if (rep > 0) __syncthreads();  // the previous tile's window reads are over
-    if (zero) blur_tile_f16<NW, true, ACC32>(d, tab, K, ch, tx, ty, lds, dbg);
-    else blur_tile_f16<NW, false, ACC32>(d, tab, K, ch, tx, ty, lds, dbg);
+    if (zero) blur_tile_f16<NW, true, ACC>(d, tab, K, ch, tx, ty, lds, dbg);
+    else blur_tile_f16<NW, false, ACC>(d, tab, K, ch, tx, ty, lds, dbg);
   }
 }
 
@@ -460,7 +476,7 @@ template <> struct Arith<float> {
   static __device__ V weight(unsigned bits) { return __uint_as_float(bits); }
 };
 
-template <typename T, bool ACC32>
+template <typename T, int ACC>
 __global__ __launch_bounds__(256) void blur_generic_kernel(BlurBatch batch, const int *__restrict__ tables, int K) {
 #pragma clang fp contract(off)
   using V = typename Arith<T>::V;
@@ -485,14 +501,16 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(BlurBatch batch, cons
     const int sy = map_coord(y + pb - r, H, pa, pb, mode, zr);
     const int sx = map_coord(x + pb - c, W, pa, pb, mode, zc);
     V p = (zr || zc) ? V(0) : src[(size_t)sy * W + sx];
-    if constexpr (ACC32) {
+    if constexpr (ACC == DIB_ACC_FP32) {
       acc32 = acc32 + (float)p * (float)Arith<T>::weight(tap.y);
+    } else if constexpr (ACC == DIB_ACC_FMA16) {
+      acc = __builtin_fmaf16(p, Arith<T>::weight(tap.y), acc);   // native fp16 fma: one rounding
     } else {
       V prod = p * Arith<T>::weight(tap.y);
       acc = acc + prod;
     }
   }
-  reinterpret_cast<V *>(d.out)[e] = ACC32 ? (V)acc32 : acc;
+  reinterpret_cast<V *>(d.out)[e] = ACC == DIB_ACC_FP32 ? (V)acc32 : acc;
 }
 
 }  // namespace dib
@@ -517,8 +535,8 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   }
   if (K != 128 && K != 256) { set_error("dib_sparse_blur: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
   if (dtype != DIB_F16 && dtype != DIB_F32) { set_error("dib_sparse_blur: unknown dtype %d", dtype); return DIB_EINVAL; }
-  if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FP32) { set_error("dib_sparse_blur: unknown accumulation mode %d", acc_mode); return DIB_EINVAL; }
-  if (acc_mode == DIB_ACC_FP32 && dtype != DIB_F16) { set_error("dib_sparse_blur: DIB_ACC_FP32 applies to fp16 images only (fp32 images already accumulate in fp32)"); return DIB_EINVAL; }
+  if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FP32 && acc_mode != DIB_ACC_FMA16) { set_error("dib_sparse_blur: unknown accumulation mode %d", acc_mode); return DIB_EINVAL; }
+  if (acc_mode != DIB_ACC_BITEXACT && dtype != DIB_F16) { set_error("dib_sparse_blur: DIB_ACC_FP32 / DIB_ACC_FMA16 apply to fp16 images only (fp32 images already accumulate in fp32)"); return DIB_EINVAL; }
   for (int i = 0; i < B; ++i) {
     if (table_index[i] < 0) continue;
     if (!in_dev[i] || !out_dev[i] || C[i] <= 0 || H[i] <= 0 || W[i] <= 0) {
@@ -539,13 +557,14 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   static bool attr_set = false;
   if (!attr_set) {
     DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 1, DIB_ACC_FP32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 1, DIB_ACC_FMA16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     DIB_HIP_CHECK(hipFuncSetAttribute((const void *)blur_tiled_f16_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
-  const int tpw = (acc_mode == DIB_ACC_FP32) ? 1 : g_tpw;  // the fp32-accumulate kernel exists as <4, 1> only
+  const int tpw = (acc_mode != DIB_ACC_BITEXACT) ? 1 : g_tpw;  // the other modes exist as <4, 1> only
   int i = 0;
   while (i < B) {
     BlurBatch tiled, generic;
@@ -586,13 +605,14 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     }
     if (dtype == DIB_F16) {
       for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
-      if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1, true>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1, DIB_ACC_FP32>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1, DIB_ACC_FMA16>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else if (g_nw == 4 && g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 1>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else if (g_nw == 4) hipLaunchKernelGGL((blur_tiled_f16_kernel<4, 2>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else if (g_tpw == 1) hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 1>), dim3(grid), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else hipLaunchKernelGGL((blur_tiled_f16_kernel<8, 2>), dim3(grid), dim3(512), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
     } else {
-      hipLaunchKernelGGL((blur_generic_kernel<float, false>), dim3(gblocks), dim3(256), 0, s, generic, (const int *)tables_dev, K);
+      hipLaunchKernelGGL((blur_generic_kernel<float, DIB_ACC_BITEXACT>), dim3(gblocks), dim3(256), 0, s, generic, (const int *)tables_dev, K);
     }
     DIB_HIP_CHECK(hipGetLastError());
   }
@@ -614,11 +634,13 @@ extern "C" int dib_sparse_blur_generic(const void *in_dev, void *out_dev, int C,
   g.xcd_bands = 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DIB_F16)
-    hipLaunchKernelGGL((blur_generic_kernel<__half, false>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
+    hipLaunchKernelGGL((blur_generic_kernel<__half, DIB_ACC_BITEXACT>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
   else if (dtype == DIB_F32)
-    hipLaunchKernelGGL((blur_generic_kernel<float, false>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
-  else  // dtype 2: fp16 image, DIB_ACC_FP32 arithmetic
-    hipLaunchKernelGGL((blur_generic_kernel<__half, true>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
+    hipLaunchKernelGGL((blur_generic_kernel<float, DIB_ACC_BITEXACT>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
+  else if (dtype == 2)  // fp16 image, DIB_ACC_FP32 arithmetic
+    hipLaunchKernelGGL((blur_generic_kernel<__half, DIB_ACC_FP32>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
+  else  // dtype 3: fp16 image, DIB_ACC_FMA16 arithmetic
+    hipLaunchKernelGGL((blur_generic_kernel<__half, DIB_ACC_FMA16>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }

@@ -40,6 +40,8 @@ extern "C" {
 #define DIB_ACC_BITEXACT 0 /* reference arithmetic: round after every multiply and every add,
                               taps in row-major order (blur_functions.py:66-67)               */
 #define DIB_ACC_FP32 1     /* fp32 accumulate, one final rounding (fp16 images only)           */
+#define DIB_ACC_FMA16 2    /* fp16 accumulate with a fused multiply-add: one rounding per tap
+                              instead of two; half the arithmetic, not the reference's (fp16 only) */
 
 int dib_abi_version(void);
 const char *dib_last_error(void);

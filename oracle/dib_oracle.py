@@ -320,12 +320,15 @@ def _pad_index(s, n, mode):
     return np.where((s < 0) | (s > n - 1), -1, s)
 
 
-def manual_blur(image, psf_norm, fp32_accumulate=False):
+def manual_blur(image, psf_norm, fp32_accumulate=False, fma16=False):
     """models/blur_functions.py:11-69 (both canvas branches), post-ops excluded.
 
     fp32_accumulate=True restates the library's DIB_ACC_FP32 mode instead of the reference
     arithmetic (fp16 images only): the fp16 x fp16 products are exact in float32, the running sum is
     float32, taps in the same order, one rounding to fp16 at the end.
+    fma16=True restates DIB_ACC_FMA16: acc = fp16(acc + P * w) with ONE rounding per tap (a fused
+    multiply-add in fp16).  float64 holds acc + P * w exactly whenever the rounding could go either way
+    (22-bit product, 11-bit accumulator), so rounding the float64 sum to fp16 is the fused result.
 
     image: C x H x W float16 or float32;  psf_norm: K x K, same dtype, already normalised.
     out[ch,y,x] = sum over taps (r,c), row-major, of  rnd(rnd(P[(y+2pb-r) mod Hp, (x+2pb-c) mod Wp] * w) + acc)
@@ -358,7 +361,9 @@ def manual_blur(image, psf_norm, fp32_accumulate=False):
         g = image[:, np.maximum(pr, 0)][:, :, np.maximum(pc, 0)]
         if mode == "constant":
             g = g * ((pr >= 0)[None, :, None] & (pc >= 0)[None, None, :]).astype(dt)
-        if fp32_accumulate:
+        if fma16:
+            acc = (acc.astype(np.float64) + g.astype(np.float64) * np.float64(w)).astype(dt)
+        elif fp32_accumulate:
             acc = acc + g.astype(np.float32) * np.float32(w)
         else:
             acc = (acc + (g * dt.type(w)).astype(dt)).astype(dt)

@@ -57,17 +57,20 @@ def test_random_batches_bit_exact(seed):
 
 
 @pytest.mark.parametrize("seed", range(2))
-def test_random_images_fp32_accumulate_bit_exact(seed):
-    """The same random population through DIB_ACC_FP32, against the oracle's restatement of that mode."""
+@pytest.mark.parametrize("mode", ["fp32", "fma16"])
+def test_random_images_other_accumulation_modes_bit_exact(seed, mode):
+    """The same random population through DIB_ACC_FP32 / DIB_ACC_FMA16, against the oracle's restatement
+    of each mode."""
     from detectinblur_amd import _lib
     from detectinblur_amd.models import blur_functions as BF
     rs = np.random.RandomState(5000 + seed)
+    acc = _lib.DIB_ACC_FP32 if mode == "fp32" else _lib.DIB_ACC_FMA16
     for _ in range(int(os.environ.get("DIB_FUZZ_CASES", "10"))):
         img, psf = _case(rs)
         pn = O.normalize_psf(psf)
-        want = O.manual_blur(img, pn, fp32_accumulate=True)
-        got = BF.manual_blur(torch.from_numpy(img).cuda(), torch.from_numpy(pn).cuda(), acc_mode=_lib.DIB_ACC_FP32).cpu().numpy()
-        assert got.shape == want.shape and np.array_equal(got.view(np.uint16), want.view(np.uint16)), (seed, img.shape)
+        want = O.manual_blur(img, pn, fp32_accumulate=(mode == "fp32"), fma16=(mode == "fma16"))
+        got = BF.manual_blur(torch.from_numpy(img).cuda(), torch.from_numpy(pn).cuda(), acc_mode=acc).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint16), want.view(np.uint16)), (seed, mode, img.shape)
 
 
 @pytest.mark.parametrize("seed", range(2))

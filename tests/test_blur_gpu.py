@@ -275,6 +275,35 @@ def test_acc_fp32_mode_bit_exact_vs_oracle_and_within_tolerance_of_reference(gol
     assert np.array_equal(_bits(out.cpu().numpy().squeeze()), _bits(want))
 
 
+ACC_FMA16_TOL = 1e-2   # stated tolerance of the fused-FMA mode vs the reference's fp16 arithmetic (images in [0, 1])
+
+
+@pytest.mark.parametrize("case", [c for c in GI.blur_cases() if not c.get("digest_only")], ids=lambda c: c["name"])
+def test_acc_fma16_mode_bit_exact_vs_oracle_and_within_tolerance_of_reference(golden, case):
+    """Fused-FMA mode (one rounding per tap): bit-identical to its CPU restatement for the tiled and
+    the generic kernel, within 1e-2 (scaled by the image magnitude) of the reference's result."""
+    from detectinblur_amd import _lib, blur_ops
+    from detectinblur_amd.models import blur_functions as BF
+    img = GI.make_image(case)
+    psf = GI.make_case_psf(case)
+    if img.dtype != np.float16:
+        with pytest.raises(_lib.DibError, match="fp16 images only"):
+            BF.manual_blur(_dev(img), _dev(psf), acc_mode=_lib.DIB_ACC_FMA16)
+        return
+    want = O.manual_blur(img, psf, fma16=True)
+    got = BF.manual_blur(_dev(img), _dev(psf), acc_mode=_lib.DIB_ACC_FMA16).cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(want))
+    ref = golden.blur["blur_" + case["name"]].view(np.float16)
+    assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() <= ACC_FMA16_TOL * max(1.0, float(np.abs(img).max()))
+    t_img = _dev(img)
+    tabs = blur_ops.compact_psfs([_dev(psf)], normalize=False)
+    out = torch.empty_like(t_img)
+    C, H, W = img.shape
+    _lib.check(_lib.lib().dib_sparse_blur_generic(t_img.data_ptr(), out.data_ptr(), C, H, W, 3, tabs.ptr(0), psf.shape[0],
+                                                  torch.cuda.current_stream().cuda_stream))
+    assert np.array_equal(_bits(out.cpu().numpy().squeeze()), _bits(want))
+
+
 def test_acc_fp32_mode_full_size_batch():
     """configs[1] shape in fp32-accumulate mode: batch == per-image calls, one image checked against
     the oracle on a strided sample of rows (the full oracle pass takes minutes at this size)."""

@@ -100,6 +100,21 @@ def test_fp32_accumulate_mode_within_stated_tolerance(golden, case):
     assert np.abs(out.astype(np.float64) - want.astype(np.float64)).max() <= ACC_FP32_TOL * max(1.0, float(np.abs(img).max()))
 
 
+ACC_FMA16_TOL = 1e-2
+
+
+@pytest.mark.parametrize("case", [c for c in GI.blur_cases() if not c.get("digest_only") and c.get("dtype", "float16") == "float16"],
+                         ids=lambda c: c["name"])
+def test_fma16_mode_within_stated_tolerance(golden, case):
+    img = GI.make_image(case)
+    if img.dtype != np.float16:
+        pytest.skip("fp16 images only")
+    out = O.manual_blur(img, GI.make_case_psf(case), fma16=True)
+    want = golden.blur["blur_" + case["name"]].view(np.float16)
+    assert out.dtype == np.float16 and out.shape == want.shape
+    assert np.abs(out.astype(np.float64) - want.astype(np.float64)).max() <= ACC_FMA16_TOL * max(1.0, float(np.abs(img).max()))
+
+
 def test_manual_blur_coco_size_digest(golden):
     case = [c for c in GI.blur_cases() if c["name"] == "coco_e2_f16"][0]
     out = O.manual_blur(GI.make_image(case), GI.make_case_psf(case))
