@@ -54,6 +54,7 @@ template <> struct Elem<__half> {
   static __device__ __half div(__half a, __half b) { return __float2half_rn(__half2float(a) / __half2float(b)); }
   static __device__ bool nonzero(__half v) { return (__half_as_ushort(v) & 0x7fff) != 0; }
   static __device__ unsigned bits(__half v) { return __half_as_ushort(v); }
+  static __device__ __half from_bits(unsigned b) { return __ushort_as_half((unsigned short)b); }
 };
 template <> struct Elem<float> {
   // fp32 PSFs (manual_blur with fp32 operands): torch's fp32 sum order is implementation
@@ -64,12 +65,59 @@ template <> struct Elem<float> {
   static __device__ float div(float a, float b) { return a / b; }
   static __device__ bool nonzero(float v) { return v != 0.0f; }
   static __device__ unsigned bits(float v) { return __float_as_uint(v); }
+  static __device__ float from_bits(unsigned b) { return __uint_as_float(b); }
 };
 
 template <typename A> __device__ inline A wave_sum(A v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
+
+// ---- wave64 reductions / scan on the DPP path -------------------------------------------------------
+// __shfl_* compile to ds_bpermute_b32: ~100 cycles of latency each, and a 6-step reduction is a chain
+// of them (x2 for 64-bit values).  Row-level DPP moves run at VALU rate; the four row results are
+// collected with v_readlane.  dpp0: lanes without a source read 0; dppk: they keep `keep`.
+template <int CTRL> __device__ inline int dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ inline int dppk(int v, int keep) { return __builtin_amdgcn_update_dpp(keep, v, CTRL, 0xf, 0xf, false); }
+constexpr int QUAD_SWAP1 = 0xB1, QUAD_SWAP2 = 0x4E, ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118;
+
+__device__ inline int wave_sum_i32(int x) {   // wave-uniform result
+  x += dpp0<QUAD_SWAP1>(x); x += dpp0<QUAD_SWAP2>(x);   // every lane: its quad's sum
+  x += dpp0<ROW_SHR4>(x); x += dpp0<ROW_SHR8>(x);       // lanes 12..15 of a row: the row's sum
+  return __builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31) + __builtin_amdgcn_readlane(x, 47) +
+         __builtin_amdgcn_readlane(x, 63);
+}
+__device__ inline int wave_min_i32(int x) {
+  x = min(x, dppk<QUAD_SWAP1>(x, x)); x = min(x, dppk<QUAD_SWAP2>(x, x));
+  x = min(x, dppk<ROW_SHR4>(x, x)); x = min(x, dppk<ROW_SHR8>(x, x));
+  return min(min(__builtin_amdgcn_readlane(x, 15), __builtin_amdgcn_readlane(x, 31)),
+             min(__builtin_amdgcn_readlane(x, 47), __builtin_amdgcn_readlane(x, 63)));
+}
+__device__ inline int wave_max_i32(int x) {
+  x = max(x, dppk<QUAD_SWAP1>(x, x)); x = max(x, dppk<QUAD_SWAP2>(x, x));
+  x = max(x, dppk<ROW_SHR4>(x, x)); x = max(x, dppk<ROW_SHR8>(x, x));
+  return max(max(__builtin_amdgcn_readlane(x, 15), __builtin_amdgcn_readlane(x, 31)),
+             max(__builtin_amdgcn_readlane(x, 47), __builtin_amdgcn_readlane(x, 63)));
+}
+__device__ inline int wave_scan_incl_i32(int x, int lane) {   // inclusive prefix sum over the 64 lanes
+  x += dpp0<ROW_SHR1>(x); x += dpp0<ROW_SHR2>(x); x += dpp0<ROW_SHR4>(x); x += dpp0<ROW_SHR8>(x);
+  const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
+  const int row = lane >> 4;
+  return x + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
+}
+// exact 64-bit sum as three limbs (21 + 21 + 22 bits): every limb's 64-lane sum fits 32 bits, and the
+// recombination is arithmetic mod 2^64, so negative (two's complement) inputs come out right
+__device__ inline long long wave_sum(long long v) {
+  const unsigned long long u = (unsigned long long)v;
+  const unsigned long long s0 = (unsigned)wave_sum_i32((int)(u & 0x1fffffu));
+  const unsigned long long s1 = (unsigned)wave_sum_i32((int)((u >> 21) & 0x1fffffu));
+  const unsigned long long s2 = (unsigned)wave_sum_i32((int)(u >> 42));
+  return (long long)(s0 + (s1 << 21) + (s2 << 42));
+}
+
+// sum over the wave, same value in every lane
+__device__ inline long long wave_total(long long v) { return wave_sum(v); }                 // limb path: already uniform
+__device__ inline double wave_total(double v) { return __shfl(wave_sum(v), 0, 64); }         // shuffle path: lane 0 holds it
 
 constexpr int CT = 1024;          // threads per PSF
 constexpr int STAGE_TAPS = 4096;  // (row<<8|col) of the first taps are staged in LDS for the segmenter
@@ -85,9 +133,9 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   __shared__ typename E::Acc s_part[NWAVE];
   __shared__ int s_wtot[NWAVE];
   __shared__ int s_ext[4];  // rmin rmax cmin cmax
-  __shared__ T s_sum;
   __shared__ unsigned short s_rc[STAGE_TAPS];
-  __shared__ unsigned short s_w16[STAGE_TAPS];
+  __shared__ unsigned s_wb[STAGE_TAPS];      // weight bits (raw before the division, final after)
+  __shared__ int s_flag;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *p = reinterpret_cast<const T *>(ptrs.p[blockIdx.x]) + (size_t)tid * EPT;
@@ -111,28 +159,114 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   }
   if (tid < 4) s_ext[tid] = (tid & 1) ? -1 : K;
 
-  // ---- sum ------------------------------------------------------------------------------------
+  // ================================ fast path ==================================================
+  // A PSF is a thin curve (15..272 non-zeros of 16,384): compact the RAW non-zeros first, then sum,
+  // divide and test only those -- one element per thread instead of EPT slots per thread.  It gives
+  // up (and the general path below redoes everything) when the non-zeros do not fit the LDS stage,
+  // when the sum is 0 / NaN (then every element becomes a NaN tap) or when a weight underflows to
+  // zero in the division (that tap has to vanish, which shifts all later positions).
+  const int e0f = tid * EPT;
+  int ntaps = 0;
+  bool fast_done = false;
   T total = T(1.0f);
-  if (normalize & 1) {
-    // A PSF is a thin curve: of the 64 x EPT elements a wave holds, a few dozen are non-zero.  Zeros
-    // add nothing, so element slots that are zero in every lane are skipped with one ballot
-    // (lifting and dividing all 16,384 elements used to be a third of this kernel's time).
-    typename E::Acc acc = 0;
+  {
+    unsigned long long rawmask = 0;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i)
-      if (__builtin_amdgcn_ballot_w64(E::nonzero(v[i])) != 0) acc += E::lift(v[i]);
-    acc = wave_sum(acc);
+    for (int i = 0; i < EPT; ++i) rawmask |= (unsigned long long)E::nonzero(v[i]) << i;
+    const int rcnt = __popcll(rawmask);
+    const bool wave_busy = __builtin_amdgcn_ballot_w64(rcnt != 0) != 0;
+    const int rincl = wave_busy ? wave_scan_incl_i32(rcnt, lane) : 0;
+    if (lane == 63) s_wtot[wave] = rincl;
+    if (tid == 0) s_flag = 0;
+    __syncthreads();                                                     // A
+    const int wt = lane < NWAVE ? s_wtot[lane] : 0;
+    const int wincl = wave_scan_incl_i32(wt, lane);
+    const int n_raw = __builtin_amdgcn_readlane(wincl, NWAVE - 1);
+    const int rbase = __builtin_amdgcn_readlane(wincl - wt, wave);
+    const int rpos = rbase + rincl - rcnt;                               // this thread's first raw tap
+    bool ok = n_raw <= STAGE_TAPS;
+    if (ok && wave_busy) {
+      int q = rpos;
+#pragma unroll
+      for (int i = 0; i < EPT; ++i)
+        if (rawmask & (1ull << i)) {
+          s_rc[q] = (unsigned short)((((e0f + i) >> LK) << 8) | ((e0f + i) & (K - 1)));
+          s_wb[q] = E::bits(v[i]);
+          ++q;
+        }
+    }
+    __syncthreads();                                                     // B: raw taps staged in row-major order
+    if (ok && (normalize & 1)) {
+      typename E::Acc acc = 0;
+      for (int j = tid; j < n_raw; j += CT) acc += E::lift(E::from_bits(s_wb[j]));
+      const bool wbusy = __builtin_amdgcn_ballot_w64(tid < n_raw) != 0;
+      if (wbusy) acc = wave_sum(acc);
+      if (lane == 0) s_part[wave] = acc;
+      __syncthreads();                                                   // C
+      typename E::Acc part = lane < NWAVE ? s_part[lane] : typename E::Acc(0);
+      total = E::finish(wave_total(part));
+      ok = (float)total == (float)total && E::nonzero(total);
+    }
+    if (ok) {
+      uint2 *taps_f = reinterpret_cast<uint2 *>(tab + table_taps_off(K));
+      for (int j = tid; j < n_raw; j += CT) {
+        T w = E::from_bits(s_wb[j]);
+        if (normalize & 1) w = E::div(w, total);
+        if (!E::nonzero(w)) s_flag = 1;                                  // underflow: give up
+        taps_f[j] = make_uint2((unsigned)s_rc[j], E::bits(w));
+        s_wb[j] = E::bits(w);
+      }
+    }
+    __syncthreads();                                                     // D
+    ok = ok && s_flag == 0;
+    if (ok) {
+      constexpr int TPRF = K / EPT;  // threads per PSF row
+      if ((tid % TPRF) == 0) tab[table_rowptr_off() + tid / TPRF] = rpos;
+      if (wave == 0) {
+        // extents: rows from the first / last tap (row-major order), columns by a reduction
+        int cmn = K, cmx = -1;
+        for (int j = lane; j < n_raw; j += 64) { const int c = s_rc[j] & 255; cmn = min(cmn, c); cmx = max(cmx, c); }
+        cmn = wave_min_i32(cmn); cmx = wave_max_i32(cmx);
+        if (lane == 0) {
+          tab[table_rowptr_off() + K] = n_raw;
+          tab[HDR_NTAPS] = n_raw;
+          tab[HDR_RMIN] = n_raw ? (s_rc[0] >> 8) : K; tab[HDR_RMAX] = n_raw ? (s_rc[n_raw - 1] >> 8) : -1;
+          tab[HDR_CMIN] = cmn; tab[HDR_CMAX] = cmx;
+          tab[HDR_K] = K; tab[HDR_SUM] = (int)E::bits(total);
+        }
+      }
+      ntaps = n_raw;
+      fast_done = true;
+    }
+  }
+  uint2 *taps = reinterpret_cast<uint2 *>(tab + table_taps_off(K));
+  if (!fast_done) {
+  // ================================ general path ===============================================
+  // A PSF is a thin curve: most of the 16 waves hold nothing but zeros.  One ballot per wave settles that
+  // (`busy`); a busy wave still skips every element slot that is zero in all its lanes.  Lifting, dividing
+  // and testing all 16,384 elements one by one used to be most of this kernel's time.
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) any = any || E::nonzero(v[i]);
+  const bool busy = __builtin_amdgcn_ballot_w64(any) != 0;   // wave-uniform
+
+  // ---- sum ------------------------------------------------------------------------------------
+  total = T(1.0f);
+  if (normalize & 1) {
+    typename E::Acc acc = 0;
+    if (busy) {
+#pragma unroll
+      for (int i = 0; i < EPT; ++i)
+        if (__builtin_amdgcn_ballot_w64(E::nonzero(v[i])) != 0) acc += E::lift(v[i]);
+      acc = wave_sum(acc);
+    }
     if (lane == 0) s_part[wave] = acc;
     __syncthreads();
-    if (tid == 0) {
-      typename E::Acc a = 0;
-      for (int k = 0; k < NWAVE; ++k) a += s_part[k];
-      s_sum = E::finish(a);
-    }
-    __syncthreads();
-    total = s_sum;
+    // every wave adds the 16 partials itself (lane k takes partial k): no second barrier, no serial loop
+    typename E::Acc part = lane < NWAVE ? s_part[lane] : typename E::Acc(0);
+    total = E::finish(wave_total(part));
   } else {
-    __syncthreads();
+    __syncthreads();   // s_ext is initialised before any wave's atomics below
   }
 
   // ---- weights, non-zero mask, extents ----------------------------------------------------------
@@ -142,33 +276,37 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   // 0 / total is 0 unless total is 0 or NaN (then the reference's psf / psf.sum() is NaN everywhere and
   // every element becomes a tap): only in that case are all-zero slots divided too
   const bool sane = (float)total == (float)total && E::nonzero(total);
+  if (busy || !sane) {
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    if (sane && __builtin_amdgcn_ballot_w64(E::nonzero(v[i])) == 0) continue;
-    if (normalize & 1) v[i] = E::div(v[i], total);
-    if (E::nonzero(v[i])) {
-      mask |= 1ull << i;
-      const int r = (e0 + i) >> LK, c = (e0 + i) & (K - 1);
-      rmin = min(rmin, r); rmax = max(rmax, r); cmin = min(cmin, c); cmax = max(cmax, c);
+    for (int i = 0; i < EPT; ++i) {
+      if (sane && __builtin_amdgcn_ballot_w64(E::nonzero(v[i])) == 0) continue;
+      if (normalize & 1) v[i] = E::div(v[i], total);
+      if (E::nonzero(v[i])) {
+        mask |= 1ull << i;
+        const int r = (e0 + i) >> LK, c = (e0 + i) & (K - 1);
+        rmin = min(rmin, r); rmax = max(rmax, r); cmin = min(cmin, c); cmax = max(cmax, c);
+      }
     }
   }
   const int cnt = __popcll(mask);
-  for (int off = 32; off > 0; off >>= 1) {
-    rmin = min(rmin, __shfl_down(rmin, off, 64)); rmax = max(rmax, __shfl_down(rmax, off, 64));
-    cmin = min(cmin, __shfl_down(cmin, off, 64)); cmax = max(cmax, __shfl_down(cmax, off, 64));
-  }
-  if (lane == 0) {
-    atomicMin(&s_ext[0], rmin); atomicMax(&s_ext[1], rmax);
-    atomicMin(&s_ext[2], cmin); atomicMax(&s_ext[3], cmax);
-  }
-
-  // ---- exclusive scan of the per-thread counts ----------------------------------------------------
   int incl = cnt;
-  for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+  if (busy || !sane) {
+    rmin = wave_min_i32(rmin); rmax = wave_max_i32(rmax);
+    cmin = wave_min_i32(cmin); cmax = wave_max_i32(cmax);
+    if (lane == 0) {
+      atomicMin(&s_ext[0], rmin); atomicMax(&s_ext[1], rmax);
+      atomicMin(&s_ext[2], cmin); atomicMax(&s_ext[3], cmax);
+    }
+    // ---- inclusive scan of the per-thread counts inside the wave ----------------------------------
+    incl = wave_scan_incl_i32(cnt, lane);
+  }
   if (lane == 63) s_wtot[wave] = incl;
   __syncthreads();
-  int wbase = 0, ntaps = 0;
-  for (int k = 0; k < NWAVE; ++k) { if (k < wave) wbase += s_wtot[k]; ntaps += s_wtot[k]; }
+  // wave totals -> bases: lane k takes wave k's total, a 16-lane scan gives every wave its base
+  int wt = lane < NWAVE ? s_wtot[lane] : 0;
+  const int wincl = wave_scan_incl_i32(wt, lane);
+  ntaps = __builtin_amdgcn_readlane(wincl, NWAVE - 1);
+  const int wbase = __builtin_amdgcn_readlane(wincl - wt, wave);
   int pos = wbase + incl - cnt;
 
   // ---- header, CSR row pointers, taps -----------------------------------------------------------------
@@ -180,18 +318,19 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
     tab[HDR_RMIN] = s_ext[0]; tab[HDR_RMAX] = s_ext[1]; tab[HDR_CMIN] = s_ext[2]; tab[HDR_CMAX] = s_ext[3];
     tab[HDR_K] = K; tab[HDR_SUM] = (int)E::bits(total);
   }
-  uint2 *taps = reinterpret_cast<uint2 *>(tab + table_taps_off(K));
+  if (__builtin_amdgcn_ballot_w64(mask != 0) != 0)
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     if (mask & (1ull << i)) {
       const unsigned rc = (unsigned)(((e0 + i) >> LK) << 8 | ((e0 + i) & (K - 1)));
       taps[pos] = make_uint2(rc, E::bits(v[i]));
-      if (pos < STAGE_TAPS) { s_rc[pos] = (unsigned short)rc; s_w16[pos] = (unsigned short)E::bits(v[i]); }
+      if (pos < STAGE_TAPS) { s_rc[pos] = (unsigned short)rc; s_wb[pos] = E::bits(v[i]); }
       ++pos;
     }
   }
   __threadfence_block();
   __syncthreads();
+  }  // general path
   if (wave != 0) return;
   if (normalize & 4) return;  // diagnostics: skip the segmentation
 
@@ -202,7 +341,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   auto emit_ltaps = [&](int s0, int s1, int rl, int cmx) {
     for (int j = s0 + lane; j < s1; j += 64) {
       unsigned rcj, wj;
-      if (j < STAGE_TAPS) { rcj = s_rc[j]; wj = s_w16[j]; }
+      if (j < STAGE_TAPS) { rcj = s_rc[j]; wj = s_wb[j] & 0xffffu; }
       else { const uint2 tp = taps[j]; rcj = tp.x & 0xffffu; wj = tp.y & 0xffffu; }
       const int rj = rcj >> 8, cj = rcj & 255;
       ltaps[j] = (unsigned)(((rl - rj) * WIN_PITCH + (cmx - cj)) * 8) | (wj << 16);
