@@ -105,6 +105,20 @@ __device__ inline int wave_scan_incl_i32(int x, int lane) {   // inclusive prefi
   const int row = lane >> 4;
   return x + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
 }
+__device__ inline int wave_scan_min_i32(int x, int lane) {   // inclusive prefix minimum (identity: INT_MAX)
+  constexpr int ID = 0x7fffffff;
+  x = min(x, dppk<ROW_SHR1>(x, ID)); x = min(x, dppk<ROW_SHR2>(x, ID)); x = min(x, dppk<ROW_SHR4>(x, ID)); x = min(x, dppk<ROW_SHR8>(x, ID));
+  const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
+  const int row = lane >> 4;
+  return min(x, min(row > 0 ? r0 : ID, min(row > 1 ? r1 : ID, row > 2 ? r2 : ID)));
+}
+__device__ inline int wave_scan_max_i32(int x, int lane) {   // inclusive prefix maximum (identity: INT_MIN)
+  constexpr int ID = (int)0x80000000;
+  x = max(x, dppk<ROW_SHR1>(x, ID)); x = max(x, dppk<ROW_SHR2>(x, ID)); x = max(x, dppk<ROW_SHR4>(x, ID)); x = max(x, dppk<ROW_SHR8>(x, ID));
+  const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
+  const int row = lane >> 4;
+  return max(x, max(row > 0 ? r0 : ID, max(row > 1 ? r1 : ID, row > 2 ? r2 : ID)));
+}
 // exact 64-bit sum as three limbs (21 + 21 + 22 bits): every limb's 64-lane sum fits 32 bits, and the
 // recombination is arithmetic mod 2^64, so negative (two's complement) inputs come out right
 __device__ inline long long wave_sum(long long v) {
@@ -354,33 +368,30 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
     unsigned rc = 0;
     if (valid) rc = (i < STAGE_TAPS) ? s_rc[i] : (taps[i].x & 0xffffu);
     const int r = rc >> 8, c = rc & 255;
-    if (base == 0) seg_r0 = __shfl(r, 0, 64);
+    if (base == 0) seg_r0 = __builtin_amdgcn_readlane(r, 0);
     int lo = 0;
     while (true) {
       // inclusive prefix min / max of c over lanes [lo, lane], joined with the open segment's carry
-      int pm = (valid && lane >= lo) ? c : (1 << 20), px = (valid && lane >= lo) ? c : -1;
-      for (int off = 1; off < 64; off <<= 1) {
-        int a = __shfl_up(pm, off, 64), b = __shfl_up(px, off, 64);
-        if (lane >= off) { pm = min(pm, a); px = max(px, b); }
-      }
+      int pm = wave_scan_min_i32((valid && lane >= lo) ? c : (1 << 20), lane);
+      int px = wave_scan_max_i32((valid && lane >= lo) ? c : -1, lane);
       pm = min(pm, car_cmin); px = max(px, car_cmax);
       const bool bad = valid && lane >= lo && ((r - seg_r0 > SEG_ROWS) || (px - pm > SEG_COLS));
       const unsigned long long fail = __ballot(bad);
       const unsigned long long vmask = __ballot(valid);
       const int last_valid = 63 - __clzll((long long)vmask);  // vmask != 0 inside the loop
       if (fail == 0) {
-        car_cmin = __shfl(pm, last_valid, 64); car_cmax = __shfl(px, last_valid, 64);
-        seg_rlast = __shfl(r, last_valid, 64);
+        car_cmin = __builtin_amdgcn_readlane(pm, last_valid); car_cmax = __builtin_amdgcn_readlane(px, last_valid);
+        seg_rlast = __builtin_amdgcn_readlane(r, last_valid);
         break;
       }
       const int f = __ffsll((long long)fail) - 1;  // tap base+f opens a new segment
       int cmn = car_cmin, cmx = car_cmax, rl = seg_rlast;
-      if (f > lo) { cmn = __shfl(pm, f - 1, 64); cmx = __shfl(px, f - 1, 64); rl = __shfl(r, f - 1, 64); }
+      if (f > lo) { cmn = __builtin_amdgcn_readlane(pm, f - 1); cmx = __builtin_amdgcn_readlane(px, f - 1); rl = __builtin_amdgcn_readlane(r, f - 1); }
       if (lane == 0) segs[nseg] = make_uint4(seg_start, base + f, (seg_r0 << 8) | rl, (cmn << 8) | cmx);
       emit_ltaps(seg_start, base + f, rl, cmx);
       ++nseg;
       seg_start = base + f;
-      seg_r0 = __shfl(r, f, 64);
+      seg_r0 = __builtin_amdgcn_readlane(r, f);
       seg_rlast = seg_r0;
       car_cmin = 1 << 20; car_cmax = -1;
       lo = f;
