@@ -404,10 +404,10 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
   }
 }
 
-// Grid: one 256-thread workgroup per (image, channel, 256 x 32 tile) in the flattened order
-// [image][channel][ty][tx]; four workgroups fit a CU (36 KB of LDS each).  Consecutive tiles land on
-// different XCDs (round-robin dispatch), which spreads every image -- and its tap count -- evenly
-// over the chip; the hardware dispatcher refills a CU as soon as a workgroup retires.
+// Grid: one 256-thread workgroup per (image, channel, 256 x 32 tile); four workgroups fit a CU (36 KB
+// of LDS each) and the hardware dispatcher refills a CU as soon as a workgroup retires.  The tile a
+// workgroup takes is NOT blockIdx in the flattened [image][channel][ty][tx] order: see "Tile order"
+// at the top of the kernel (per-XCD bands of every image).
 // (Measured alternatives, scratch/: a persistent kernel pulling tiles from an XCD-sharded atomic
 // queue was 30-60 % slower -- the returning atomics and the per-tile descriptor fetches sit on the
 // critical path of every tile, and static striding loses ~20 us to tap-count imbalance; 8-wave
