@@ -28,14 +28,14 @@ from .models.faster_rcnn import fasterrcnn_resnet50_fpn
 
 def get_transform(train, blur=False, blur_type=None, blur_ratio=0.5, use_stored_psfs=False, cpu_blur=False,
                   stored_psf_directory=None, dont_center_psf=False, low_exposure=False, high_exposure=False,
-                  blur_exposure=None, stored_psf_count=T.STORED_PSF_COUNT):
+                  blur_exposure=None, stored_psf_count=T.STORED_PSF_COUNT, LEHE_blur_seg=False):
     """reference train.py:48-86: [BlurImage] -> ToTensor -> [RandomHorizontalFlip(0.5) when training]."""
     tf = []
     if blur:
         tf.append(T.BlurImage(prob=blur_ratio, blur_type=blur_type, blur_exposure=blur_exposure, use_stored_psfs=use_stored_psfs,
                               stored_psf_directory=stored_psf_directory, blur_image_in_transform=cpu_blur,
                               dont_center_psf=dont_center_psf, low_exposure=low_exposure, high_exposure=high_exposure,
-                              stored_psf_count=stored_psf_count))
+                              stored_psf_count=stored_psf_count, LEHE_blur_seg=LEHE_blur_seg))
     tf.append(T.ToTensor())
     if train:
         tf.append(T.RandomHorizontalFlip(0.5))
