@@ -39,8 +39,10 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
                     add_jpeg_artifact=False):
     if writer is None:
         print("Warning! No tensorboard logger.")
-    if add_jpeg_artifact:
-        raise NotImplementedError("--add_jpeg_artefacts needs models/jpeg (DiffJPEG), outside the built path (SURVEY.md 8f)")
+    jpeg_compressor = None
+    if add_jpeg_artifact:                                                # reference :56-62
+        from .models.jpeg import DiffJPEG
+        jpeg_compressor = DiffJPEG(height=100, width=100, differentiable=False, quality=10).to(device)
     model.train()
     metric_logger = utils.MetricLogger(delimiter="  ")
     metric_logger.add_meter("lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
@@ -55,10 +57,11 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
         images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2 = _to_device(images_CPU, targets, blur_dicts, device, blur_train)
         if gpu_blur and blur_train:
             blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU=psfs_GPU, add_noise=add_noise,
-                                           noise_level=noise_level, add_block=add_block)
+                                           noise_level=noise_level, add_block=add_block,
+                                           add_jpeg_artifact=add_jpeg_artifact, jpeg_compressor=jpeg_compressor)
         if expand_target_boxes and blur_train:
             targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU)
-        images_GPU = [image.float() for image in images_GPU]
+        images_GPU = [image.float().to(device) for image in images_GPU]   # JPEG artefacts come back on the host (transforms.py:492)
         norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 
         loss_dict = model(images_GPU, targets_GPU, thetas=thetas, lambda1s=l1, lambda2s=l2, newMeans=norm_means, newSTDs=norm_stds)
@@ -126,8 +129,12 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
     """Runs the detector (or the routed ensemble) over the loader.  Returns
     {"detections": {image_id: {boxes, labels, scores}}, "targets": {image_id: expanded boxes},
      "routes": [model index per batch], "meters": MetricLogger}."""
-    if deblur_first or add_jpeg_artifact:
-        raise NotImplementedError("--deblur_first / --add_jpeg_artefacts are outside the built path (SURVEY.md section 2)")
+    if deblur_first:
+        raise NotImplementedError("--deblur_first is outside the built path (SURVEY.md section 2)")
+    jpeg_compressor = None
+    if add_jpeg_artifact:                                                # reference :248-254
+        from .models.jpeg import DiffJPEG
+        jpeg_compressor = DiffJPEG(height=100, width=100, differentiable=False, quality=10).to(device)
     n_threads = torch.get_num_threads()
     torch.set_num_threads(1)
     batcher = None
@@ -149,10 +156,11 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
         images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2 = _to_device(images_CPU, targets_CPU, blur_dicts, device, blurring_images)
         if gpu_blur and blurring_images:
             blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU=psfs_GPU, add_noise=add_noise, noise_level=noise_level,
-                                           add_block=add_block)
+                                           add_block=add_block, add_jpeg_artifact=add_jpeg_artifact,
+                                           jpeg_compressor=jpeg_compressor)
         if expand_target_boxes and blurring_images:
             targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU)
-        images_GPU = [image.float() for image in images_GPU]
+        images_GPU = [image.float().to(device) for image in images_GPU]   # JPEG artefacts come back on the host (transforms.py:492)
         norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 
         if use_ensemble:                                                 # reference :354-366

@@ -83,7 +83,7 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, resize_images=False):
     return None
 
 
-def _post(images_GPU, add_noise, noise_level, add_block, quantize_image):
+def _post(images_GPU, add_noise, noise_level, add_block, quantize_image, jpeg_compressor=None):
     for i, img in enumerate(images_GPU):                                   # reference :200-219
         if add_noise:
             noise_var = np.random.uniform(0.0001, noise_level)
@@ -93,10 +93,18 @@ def _post(images_GPU, add_noise, noise_level, add_block, quantize_image):
             s = np.random.uniform(0.6, 1)
             img = F.interpolate(img.unsqueeze(0), scale_factor=(s, s), mode="nearest").squeeze()
             img = F.interpolate(img.unsqueeze(0), size=shape[1:], mode="nearest").squeeze()
+        if jpeg_compressor is not None and np.random.uniform(0, 1) > 0.35:
+            from .transforms import add_jpeg_artifact_to_image
+            img = add_jpeg_artifact_to_image(img, jpeg_compressor, np.random.uniform(20, 90)).to(img.device)
         if quantize_image:
             img = (img * 255).type(torch.uint8).type(torch.half) / 255
         images_GPU[i] = img
     return images_GPU
+
+
+def _jpeg(device):
+    from .models.jpeg import DiffJPEG
+    return DiffJPEG(height=100, width=100, differentiable=False, quality=10).to(device)
 
 
 def _stage(images_CPU, blur_dicts, device, with_psfs):
@@ -119,8 +127,7 @@ def train_one_epoch(model, optimizer, criterion, data_loader, device, print_freq
                     writer=None, gpu_blur=False, LEHE_blur_seg=False, resize_images=False, quantize_image=False,
                     crop_images=False, add_noise=False, noise_level=0.001, add_block=False, add_jpeg_artifact=False,
                     early_stop=None, blur_train=False):
-    if add_jpeg_artifact:
-        raise NotImplementedError("DiffJPEG is outside the built hot path (SURVEY.md 8f)")
+    jpeg = _jpeg(device) if add_jpeg_artifact else None
     batcher = GeneralizedRCNNTransform(800, 1333, IMAGE_MEAN, IMAGE_STD, crop_images=crop_images)
     model.train()
     logger = utils.MetricLogger(delimiter="  ")
@@ -133,7 +140,7 @@ def train_one_epoch(model, optimizer, criterion, data_loader, device, print_freq
         images, psfs = _stage(images_CPU, blur_dicts, device, blur_train)
         if gpu_blur and blur_train:
             blur_image_list(images, blur_dicts, psfs, resize_images)
-        images = _post(images, add_noise, noise_level, add_block, quantize_image)
+        images = _post(images, add_noise, noise_level, add_block, quantize_image, jpeg)
         batch = batcher([im.float() for im in images])[0].tensors
         target = _targets(blur_dicts, device, LEHE_blur_seg)
         loss = criterion(model(batch), target)
@@ -159,8 +166,7 @@ def evaluate(model, data_loader, device, distributed_mode=False, blurring_images
              send_back_preds_targets=False, add_jpeg_artifact=False, resize_images=False, quantize_image=False,
              add_noise=False, noise_level=0.001, add_block=False, early_stop=None):
     """Top-1 / top-2 accuracy of the estimator; returns (top1, top2[, predictions, targets])."""
-    if add_jpeg_artifact:
-        raise NotImplementedError("DiffJPEG is outside the built hot path (SURVEY.md 8f)")
+    jpeg = _jpeg(device) if add_jpeg_artifact else None
     batcher = GeneralizedRCNNTransform(800, 1333, IMAGE_MEAN, IMAGE_STD)
     model.eval()
     logger = utils.MetricLogger(delimiter="  ")
@@ -170,7 +176,7 @@ def evaluate(model, data_loader, device, distributed_mode=False, blurring_images
         images, psfs = _stage(images_CPU, blur_dicts, device, blurring_images)
         if gpu_blur and blurring_images:
             blur_image_list(images, blur_dicts, psfs, resize_images)
-        images = _post(images, add_noise, noise_level, add_block, quantize_image)
+        images = _post(images, add_noise, noise_level, add_block, quantize_image, jpeg)
         out = model(batcher([im.float() for im in images])[0].tensors)
         target = _targets(blur_dicts, device, LEHE_blur_seg)
         a1, a2 = accuracy(out, target, topk=(1, 2))

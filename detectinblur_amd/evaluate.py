@@ -39,6 +39,10 @@ def build_parser():
     p.add_argument("--gpu_blur", action="store_true")
     p.add_argument("--expand_target_boxes", action="store_true")
     p.add_argument("--use_custom_image_norm", action="store_true")
+    p.add_argument("--add_noise", action="store_true")
+    p.add_argument("--noise_level", default=0.001, type=float)
+    p.add_argument("--add_block", action="store_true")
+    p.add_argument("--add_jpeg_artefacts", action="store_true", help="Add jpeg compression artifacts.")
     p.add_argument("--warp_in_model", action="store_true", help="Warp and dewarp images before and after backbone.")
     p.add_argument("--early_stop", type=int, default=None)
     p.add_argument("--world-size", default=1, type=int)
@@ -88,7 +92,8 @@ def main(args):
             out = evaluate(model, loader, device=device, distributed_mode=args.distributed, early_stop=args.early_stop,
                            blurring_images=True, gpu_blur=args.gpu_blur, expand_target_boxes=args.expand_target_boxes,
                            use_custom_image_norm=args.use_custom_image_norm, use_ensemble=args.use_ensemble, ensemble_models=ensemble,
-                           blur_estimator=estimator, LEHE=args.LEHE)
+                           blur_estimator=estimator, LEHE=args.LEHE, add_noise=args.add_noise, noise_level=args.noise_level,
+                           add_block=args.add_block, add_jpeg_artifact=args.add_jpeg_artefacts)
             results["P%dE%d" % (p_i + 1, f_i)] = out
             print("P%d E%d: %d images, routes %s" % (p_i + 1, f_i, len(out["detections"]), out["routes"][:8]))
     return results

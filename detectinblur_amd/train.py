@@ -7,7 +7,7 @@ One process per GPU, DistributedDataParallel over RCCL (backend "nccl" on ROCm),
 SGD(lr 0.04, momentum 0.9, wd 1e-4) + MultiStepLR, seeds rank*1337, per-epoch checkpoints
 {'model','optimizer','lr_scheduler','args','epoch'} and --resume / --start_from_weights
 (reference train.py:89-391).  Flags of subsystems outside the built path (AugMix, deblur-first, squint
-warp, custom BN, JPEG artefacts, real-blur datasets) are not offered.
+custom BN, real-blur datasets) are not offered.
 """
 import argparse
 import datetime
@@ -92,6 +92,7 @@ def build_parser():
     p.add_argument("--add_noise", action="store_true")
     p.add_argument("--noise_level", default=0.001, type=float)
     p.add_argument("--add_block", action="store_true")
+    p.add_argument("--add_jpeg_artefacts", action="store_true", help="Add jpeg compression artifacts.")
     p.add_argument("--use_custom_image_norm", action="store_true")
     p.add_argument("--warp_in_model", action="store_true", help="Warp and dewarp images before and after backbone.")
     p.add_argument("--world-size", default=1, type=int)
@@ -171,7 +172,7 @@ def main(args):
             train_sampler.set_epoch(epoch)
         train_one_epoch(model, optimizer, data_loader, device, epoch, args.print_freq, None, args.distributed, args.blur_train,
                         args.early_stop, args.gpu_blur, args.expand_target_boxes, args.use_custom_image_norm, args.add_noise,
-                        args.noise_level, args.add_block, False)
+                        args.noise_level, args.add_block, args.add_jpeg_artefacts)
         lr_scheduler.step()
         if args.output_dir:
             utils.mkdir(args.output_dir)
@@ -180,7 +181,8 @@ def main(args):
                                  os.path.join(args.output_dir, "model_{}.pth".format(epoch)))
         evaluate(model, data_loader_test, vanilla_eval=True, **clean_kw)
         evaluate(model, data_loader_test_blur, blurring_images=True, gpu_blur=args.gpu_blur,
-                 expand_target_boxes=args.expand_target_boxes, **eval_kw)
+                 expand_target_boxes=args.expand_target_boxes, add_noise=args.add_noise, noise_level=args.noise_level,
+                 add_block=args.add_block, add_jpeg_artifact=args.add_jpeg_artefacts, **eval_kw)
     print("Training time {}".format(str(datetime.timedelta(seconds=int(time.time() - start)))))
 
 

@@ -2,8 +2,7 @@
 
 ResNet-18 with a 16-way (or, with --LEHE_blur_seg, 4-way) head, trained on COCO images blurred on the
 GPU by the same HIP path as the detector.  One process per GPU; `torchrun` / RANK, WORLD_SIZE,
-LOCAL_RANK as in train.py.  Flags of subsystems that are out of scope (AugMix, JPEG artefacts,
-TensorBoard) are not offered.
+LOCAL_RANK as in train.py.  Flags of subsystems that are out of scope (AugMix, TensorBoard) are not offered.
 """
 import argparse
 import datetime
@@ -60,6 +59,7 @@ def build_parser():
     p.add_argument("--add_noise", action="store_true")
     p.add_argument("--noise_level", default=0.001, type=float)
     p.add_argument("--add_block", action="store_true")
+    p.add_argument("--add_jpeg_artefacts", action="store_true")
     p.add_argument("--world-size", default=1, type=int)
     p.add_argument("--dist-url", default="env://")
     return p
@@ -116,7 +116,8 @@ def main(args):
 
     eval_kw = dict(device=device, distributed_mode=args.distributed, blurring_images=True, gpu_blur=args.gpu_blur,
                    LEHE_blur_seg=args.LEHE_blur_seg, resize_images=args.resize_images, quantize_image=args.quantize_image,
-                   add_noise=args.add_noise, noise_level=args.noise_level, add_block=args.add_block, early_stop=args.early_stop)
+                   add_noise=args.add_noise, noise_level=args.noise_level, add_block=args.add_block,
+                   add_jpeg_artifact=args.add_jpeg_artefacts, early_stop=args.early_stop)
     if args.eval_first or args.test_only:
         evaluate(model, loader_test, **eval_kw)
         if args.test_only:
@@ -128,7 +129,7 @@ def main(args):
             train_sampler.set_epoch(epoch)
         train_one_epoch(model, optimizer, criterion, loader, device, args.print_freq, epoch, args.distributed, None,
                         args.gpu_blur, args.LEHE_blur_seg, args.resize_images, args.quantize_image, args.crop_images,
-                        args.add_noise, args.noise_level, args.add_block, False, args.early_stop, args.blur_train)
+                        args.add_noise, args.noise_level, args.add_block, args.add_jpeg_artefacts, args.early_stop, args.blur_train)
         scheduler.step()
         if args.output_dir:
             utils.mkdir(args.output_dir)

@@ -234,6 +234,29 @@ def gen_warper(ns, store):
     store["warp_feature"] = w(feat, th, 1 / l1, 1 / l2).numpy()
 
 
+def jpeg_input():
+    g = torch.Generator().manual_seed(2024)
+    x = torch.rand(2, 3, 32, 48, generator=g)
+    x[1] = torch.nn.functional.avg_pool2d(x[1:2], 3, 1, 1)[0]       # one smooth image
+    return x
+
+
+JPEG_QUALITIES = (20, 49, 50, 75, 90)
+
+
+def gen_jpeg(ns, store):
+    """Reference models/jpeg/DiffJPEG.py (differentiable=False) round trips on CPU."""
+    import importlib
+    J = importlib.import_module("models.jpeg.DiffJPEG")
+    x = jpeg_input()
+    m = J.DiffJPEG(height=100, width=100, differentiable=False, quality=10)
+    m.setRes(32, 48)
+    for q in JPEG_QUALITIES:
+        m.setQuality(q)
+        with torch.no_grad():
+            store["jpeg_q%d" % q] = m(x).numpy()
+
+
 PSF_STORE_RUNS = {"w0_of1_n2": (0, 1, 2), "w1_of2_n4": (1, 2, 4)}   # name -> (worker_index, num_workers, total_num_psfs)
 
 
@@ -264,6 +287,12 @@ def gen_psf_store(ns, meta):
 def main():
     ns = ref_harness.load()
     os.makedirs(OUT, exist_ok=True)
+    if "--only-jpeg" in sys.argv:
+        store = {}
+        gen_jpeg(ns, store)
+        np.savez_compressed(os.path.join(OUT, "jpeg.npz"), **store)
+        print("jpeg", {k: v.shape for k, v in store.items()})
+        return
     if "--only-warper" in sys.argv:
         store = {}
         gen_warper(ns, store)
@@ -281,7 +310,7 @@ def main():
     meta = {"numpy": np.__version__, "torch": torch.__version__}
     gen_psf_store(ns, meta)
     for name, fn in (("traj", gen_trajectories), ("psf", gen_psfs), ("boxes", gen_boxes),
-                     ("norm", gen_norm), ("fft", gen_fft), ("warper", gen_warper)):
+                     ("norm", gen_norm), ("fft", gen_fft), ("warper", gen_warper), ("jpeg", gen_jpeg)):
         store = {}
         fn(ns, store)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)

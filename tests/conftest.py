@@ -44,5 +44,6 @@ def golden():
         fft = np.load(os.path.join(d, "fft.npz"))
         blurdict = np.load(os.path.join(d, "blurdict.npz"))
         warper = np.load(os.path.join(d, "warper.npz"))
+        jpeg = np.load(os.path.join(d, "jpeg.npz"))
         meta = json.load(open(os.path.join(d, "meta.json")))
     return G

@@ -96,3 +96,15 @@ def test_evaluate_cli_ensemble_sweep_end_to_end(capsys):
     E.main(args)
     text = capsys.readouterr().out
     assert text.count("routes") == 15           # 3 blur types x 5 exposures
+
+
+def test_train_cli_with_full_corruption_chain(tmp_path, capsys):
+    """--add_noise --add_block --add_jpeg_artefacts behind the GPU blur, two iterations."""
+    from detectinblur_amd import train
+    args = train.build_parser().parse_args([
+        "--synthetic", "--synthetic_images", "4", "--synthetic_size", "160", "224", "--blur_train", "--gpu_blur",
+        "--param_index", "2", "--high_exposure", "--expand_target_boxes", "--add_noise", "--add_block", "--add_jpeg_artefacts",
+        "-b", "2", "--epochs", "1", "--early_stop", "2", "--lr", "0.002", "--print_freq", "1", "--output_dir", str(tmp_path / "run")])
+    train.main(args)
+    text = capsys.readouterr().out
+    assert "loss_classifier" in text and "Loss is" not in text
