@@ -60,6 +60,8 @@ _SIGNATURES = {
                                ctypes.c_void_p, ctypes.c_void_p]),
     "dib_nms_batched": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_coco_box_iou": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_void_p]),
     "dib_bias_act_nhwc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_void_p]),
     # test hook, not part of the drop-in boundary

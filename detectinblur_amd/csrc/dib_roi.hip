@@ -202,6 +202,31 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc_kernel(RoiLevels L, co
   }
 }
 
+// ---- COCO box IoU --------------------------------------------------------------------------------------
+// pycocotools' bbIou (reference cocoapi/common/maskApi.c:109-120): boxes as (x, y, w, h) in float64,
+// out[g * m + d] = intersection / union, with the union replaced by the DETECTION's area for crowd
+// ground truth; 0 where the boxes do not overlap.  Same float64 expression order as the C code (and
+// -ffp-contract=off), so the result is bit-identical.  One thread per (g, d) pair.
+__global__ void coco_box_iou_kernel(const double *__restrict__ dt, const double *__restrict__ gt,
+                                    const unsigned char *__restrict__ iscrowd, int m, int n, double *__restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)m * n) return;
+  const int g = (int)(idx / m), d = (int)(idx - (long long)g * m);
+  const double *G = gt + (size_t)g * 4, *D = dt + (size_t)d * 4;
+  const double ga = G[2] * G[3], da = D[2] * D[3];
+  const bool crowd = iscrowd != nullptr && iscrowd[g];
+  double o = 0;
+  const double w = fmin(D[2] + D[0], G[2] + G[0]) - fmax(D[0], G[0]);
+  if (w > 0) {
+    const double h = fmin(D[3] + D[1], G[3] + G[1]) - fmax(D[1], G[1]);
+    if (h > 0) {
+      const double i = w * h, u = crowd ? da : da + ga - i;
+      o = i / u;
+    }
+  }
+  out[idx] = o;
+}
+
 // ---- NMS ----------------------------------------------------------------------------------------
 // Pass 1: 64 x 64 blocks of the upper-triangular suppression matrix as 64-bit masks (one wave per
 // block, boxes of the column block staged in LDS).  Pass 2 (below) resolves them in score order.
@@ -377,6 +402,18 @@ extern "C" int dib_roi_align_nhwc_backward(const float *grad_out_dev, const int 
   hipLaunchKernelGGL(roi_align_bwd_nhwc_kernel, dim3(K, (C + ROI_CCHUNK - 1) / ROI_CCHUNK), dim3(256),
                      (size_t)nc * pooled * pooled * sizeof(float), (hipStream_t)stream, L, rois_dev, level_dev, C, pooled,
                      sampling_ratio, aligned, grad_out_dev);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
+
+extern "C" int dib_coco_box_iou(const double *dt_dev, const double *gt_dev, const unsigned char *iscrowd_dev, int m, int n,
+                                double *out_dev, void *stream) {
+  if (m < 0 || n < 0) { set_error("dib_coco_box_iou: negative count"); return DIB_EINVAL; }
+  if (m == 0 || n == 0) return DIB_OK;
+  if (!dt_dev || !gt_dev || !out_dev) { set_error("dib_coco_box_iou: null pointer"); return DIB_EINVAL; }
+  const long long total = (long long)m * n;
+  hipLaunchKernelGGL(coco_box_iou_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dt_dev, gt_dev,
+                     iscrowd_dev, m, n, out_dev);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }

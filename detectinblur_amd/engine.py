@@ -147,7 +147,7 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
     else:
         model.eval()
     metric_logger = utils.MetricLogger(delimiter="  ")
-    detections, gt_boxes, routes = {}, {}, []
+    detections, gt_boxes, gt_full, routes = {}, {}, {}, []
     count = 0
     for images_CPU, targets_CPU, blur_dicts in metric_logger.log_every(data_loader, 100, "Test:"):
         if device.type == "cuda":
@@ -183,6 +183,9 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
             image_id = int(t["image_id"]) if "image_id" in t else count
             detections[image_id] = o
             gt_boxes[image_id] = utils.convert_to_xywh(t["boxes"]).cpu()   # what the reference writes into coco_gt (:325-342)
+            if "labels" in t:
+                # annotations as COCOeval sees them: the (expanded) box replaces bbox, area / iscrowd stay (:325-342)
+                gt_full[image_id] = {k: t[k].detach().cpu() for k in ("boxes", "labels", "area", "iscrowd") if k in t}
         metric_logger.update(model_time=model_time)
         count += 1
         if early_stop is not None and count > early_stop:
@@ -190,4 +193,34 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     torch.set_num_threads(n_threads)
-    return {"detections": detections, "targets": gt_boxes, "routes": routes, "meters": metric_logger}
+    coco_stats = None
+    if gt_full:                                                          # reference :410-414 (CocoEvaluator)
+        coco_stats = coco_box_stats(detections, gt_full, device)
+    return {"detections": detections, "targets": gt_boxes, "routes": routes, "meters": metric_logger, "coco_stats": coco_stats}
+
+
+_STAT_NAMES = ["AP @[ IoU=0.50:0.95 | area=   all | maxDets=100 ]", "AP @[ IoU=0.50      | area=   all | maxDets=100 ]",
+               "AP @[ IoU=0.75      | area=   all | maxDets=100 ]", "AP @[ IoU=0.50:0.95 | area= small | maxDets=100 ]",
+               "AP @[ IoU=0.50:0.95 | area=medium | maxDets=100 ]", "AP @[ IoU=0.50:0.95 | area= large | maxDets=100 ]",
+               "AR @[ IoU=0.50:0.95 | area=   all | maxDets=  1 ]", "AR @[ IoU=0.50:0.95 | area=   all | maxDets= 10 ]",
+               "AR @[ IoU=0.50:0.95 | area=   all | maxDets=100 ]", "AR @[ IoU=0.50:0.95 | area= small | maxDets=100 ]",
+               "AR @[ IoU=0.50:0.95 | area=medium | maxDets=100 ]", "AR @[ IoU=0.50:0.95 | area= large | maxDets=100 ]"]
+
+
+def coco_box_stats(detections, ground_truth, device):
+    """The 12 COCO box statistics over every rank's images (detections / ground truth are gathered first);
+    the IoU runs on `device` when it is a GPU (coco_eval.CocoBoxEvaluator)."""
+    from .coco_eval import CocoBoxEvaluator
+    if utils.is_dist_avail_and_initialized():
+        merged_d, merged_g = {}, {}
+        for d, g in utils.all_gather((detections, ground_truth)):
+            merged_d.update(d)
+            merged_g.update(g)
+        detections, ground_truth = merged_d, merged_g
+    ev = CocoBoxEvaluator(ground_truth, device=device if device.type == "cuda" else None)
+    ev.update({k: v for k, v in detections.items() if k in ground_truth})
+    stats = ev.summarize()
+    if utils.is_main_process():
+        for name, v in zip(_STAT_NAMES, stats):
+            print(" Average %s (%s) %s = %0.3f" % ("Precision" if name.startswith("AP") else "Recall   ", name[:2], name[3:], v))
+    return stats

@@ -218,6 +218,22 @@ def batched_nms(boxes, scores, groups, iou_threshold):
     return nms(boxes + offsets[:, None], scores, iou_threshold)
 
 
+def coco_box_iou(dt, gt, iscrowd=None):
+    """pycocotools' bbIou on the GPU (include/dib.h: dib_coco_box_iou).  dt [m, 4], gt [n, 4]: (x, y, w, h);
+    iscrowd [n] bool / uint8 or None.  Returns float64 [m, n] laid out as maskUtils.iou returns it
+    (detections along the rows)."""
+    if not dt.is_cuda:
+        raise RuntimeError("coco_box_iou runs on the GPU (the CPU routine is pycocotools' own)")
+    d = dt.to(torch.float64).contiguous()
+    g = gt.to(device=d.device, dtype=torch.float64).contiguous()
+    m, n = d.shape[0], g.shape[0]
+    out = torch.zeros((n, m), dtype=torch.float64, device=d.device)
+    c = None if iscrowd is None else iscrowd.to(device=d.device, dtype=torch.uint8).contiguous()
+    _lib.check(_lib.lib().dib_coco_box_iou(d.data_ptr(), g.data_ptr(), c.data_ptr() if c is not None else None, m, n,
+                                           out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return out.t()
+
+
 # ------------------------------------------------------------------------------------------------
 # RoIAlign
 # ------------------------------------------------------------------------------------------------

@@ -156,6 +156,15 @@ int dib_nms_batched(const float *boxes_sorted_dev, const unsigned char *valid_de
                     void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * COCO box IoU: pycocotools' bbIou (reference cocoapi/common/maskApi.c:109-120), the inner loop of the
+ * evaluation sweep's COCOeval.  dt_dev [m][4], gt_dev [n][4]: float64 (x, y, w, h); iscrowd_dev [n]
+ * bytes or NULL; out_dev [n][m] float64 = intersection / union (union = detection area for crowd
+ * ground truth), bit-identical to the C routine.
+ * ------------------------------------------------------------------------------------- */
+int dib_coco_box_iou(const double *dt_dev, const double *gt_dev, const unsigned char *iscrowd_dev, int m, int n,
+                     double *out_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Convolution epilogue of the ResNet-50 trunk with its frozen batch-norm folded into the weights
  * (reference models/faster_rcnn.py:367 builds the trunk with torchvision's FrozenBatchNorm2d):
  *   x = act(x + bias[c] (+ residual)), in place, channels-last fp32 (channel index fastest);

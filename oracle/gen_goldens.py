@@ -257,6 +257,80 @@ def gen_jpeg(ns, store):
             store["jpeg_q%d" % q] = m(x).numpy()
 
 
+def coco_eval_inputs():
+    """Synthetic COCO-shaped ground truth and detections: 12 images, 6 categories, crowd boxes, all three
+    size classes, duplicates, misses and false positives."""
+    rs = np.random.RandomState(77)
+    gt, dt = {}, {}
+    for img in range(1, 13):
+        n = rs.randint(0, 9)
+        side = np.exp(rs.uniform(np.log(6), np.log(300), (n, 2)))
+        xy = rs.uniform(0, 400, (n, 2))
+        boxes = np.concatenate([xy, xy + side], 1)
+        labels = rs.randint(1, 7, n)
+        crowd = (rs.random_sample(n) < 0.12).astype(np.int64)
+        gt[img] = dict(boxes=boxes, labels=labels, iscrowd=crowd, area=side[:, 0] * side[:, 1] * rs.uniform(0.5, 1.0, n))
+        db, dl, ds = [], [], []
+        for b, l in zip(boxes, labels):
+            for _ in range(rs.randint(0, 3)):                      # 0..2 detections per object, jittered
+                j = b + rs.normal(0, 0.12, 4) * np.tile(b[2:] - b[:2], 2)
+                db.append([min(j[0], j[2]), min(j[1], j[3]), max(j[0], j[2]) + 1, max(j[1], j[3]) + 1])
+                dl.append(l if rs.random_sample() < 0.85 else rs.randint(1, 7)); ds.append(rs.random_sample())
+        for _ in range(rs.randint(0, 6)):                          # false positives
+            p = rs.uniform(0, 400, 2); s = np.exp(rs.uniform(np.log(6), np.log(200), 2))
+            db.append([p[0], p[1], p[0] + s[0], p[1] + s[1]]); dl.append(rs.randint(1, 7)); ds.append(rs.random_sample() * 0.8)
+        dt[img] = dict(boxes=np.asarray(db, dtype=np.float64).reshape(-1, 4), labels=np.asarray(dl, dtype=np.int64),
+                       scores=np.round(np.asarray(ds, dtype=np.float64), 3))      # rounded: ties happen
+    return gt, dt
+
+
+def gen_coco_eval(ns, store):
+    """The reference's own COCOeval (cocoapi/PythonAPI/pycocotools/{coco,cocoeval}.py, pure Python) with its
+    compiled _mask extension replaced by the reference's C bbIou (oracle/_ref/libmaskapi.so)."""
+    import importlib
+    import types
+    import ref_maskapi
+    if not hasattr(np, "float"):
+        np.float = float            # alias removed in numpy 1.24; cocoeval.py:378-379 still uses it
+    pkg_root = os.path.join(ref_harness.REFERENCE_ROOT, "cocoapi", "PythonAPI")
+    for k in [k for k in sys.modules if k == "pycocotools" or k.startswith("pycocotools.")]:
+        del sys.modules[k]
+    sys.path.insert(0, pkg_root)
+    fake = types.ModuleType("pycocotools._mask")
+    fake.iou = lambda d, g, c: ref_maskapi.bb_iou(d, g, c)
+    fake.merge = fake.frPyObjects = fake.encode = fake.decode = fake.area = fake.toBbox = None    # segmentation only
+    sys.modules["pycocotools._mask"] = fake
+    coco_mod = importlib.import_module("pycocotools.coco")
+    eval_mod = importlib.import_module("pycocotools.cocoeval")
+    gt, dt = coco_eval_inputs()
+    images, anns, res, aid = [], [], [], 1
+    for img, g in gt.items():
+        images.append({"id": img, "height": 800, "width": 800})
+        for b, l, c, a in zip(g["boxes"], g["labels"], g["iscrowd"], g["area"]):
+            anns.append({"id": aid, "image_id": img, "category_id": int(l), "bbox": [b[0], b[1], b[2] - b[0], b[3] - b[1]],
+                         "area": float(a), "iscrowd": int(c)}); aid += 1
+    for img, d in dt.items():
+        for b, l, s in zip(d["boxes"], d["labels"], d["scores"]):
+            res.append({"image_id": img, "category_id": int(l), "bbox": [b[0], b[1], b[2] - b[0], b[3] - b[1]], "score": float(s)})
+    cg = coco_mod.COCO()
+    cg.dataset = {"images": images, "annotations": anns, "categories": [{"id": i} for i in range(1, 7)]}
+    cg.createIndex()
+    cd = cg.loadRes(res)
+    ev = eval_mod.COCOeval(cg, cd, "bbox")
+    ev.evaluate(); ev.accumulate(); ev.summarize()
+    store["coco_stats"] = np.asarray(ev.stats, dtype=np.float64)
+    store["coco_precision"] = ev.eval["precision"]
+    store["coco_recall"] = ev.eval["recall"]
+    rs = np.random.RandomState(5)
+    d = np.concatenate([rs.uniform(0, 300, (40, 2)), np.exp(rs.uniform(0, 5.5, (40, 2)))], 1)
+    g = np.concatenate([rs.uniform(0, 300, (23, 2)), np.exp(rs.uniform(0, 5.5, (23, 2)))], 1)
+    g[:5] = d[:5]
+    c = (rs.random_sample(23) < 0.3).astype(np.uint8)
+    store["iou_dt"], store["iou_gt"], store["iou_crowd"] = d, g, c
+    store["iou_out"] = ref_maskapi.bb_iou(d, g, c)
+    store["iou_out_nocrowd"] = ref_maskapi.bb_iou(d, g, None)
+
+
 PSF_STORE_RUNS = {"w0_of1_n2": (0, 1, 2), "w1_of2_n4": (1, 2, 4)}   # name -> (worker_index, num_workers, total_num_psfs)
 
 
@@ -287,6 +361,12 @@ def gen_psf_store(ns, meta):
 def main():
     ns = ref_harness.load()
     os.makedirs(OUT, exist_ok=True)
+    if "--only-coco" in sys.argv:
+        store = {}
+        gen_coco_eval(ns, store)
+        np.savez_compressed(os.path.join(OUT, "coco.npz"), **store)
+        print("coco", store["coco_stats"])
+        return
     if "--only-jpeg" in sys.argv:
         store = {}
         gen_jpeg(ns, store)
@@ -310,7 +390,7 @@ def main():
     meta = {"numpy": np.__version__, "torch": torch.__version__}
     gen_psf_store(ns, meta)
     for name, fn in (("traj", gen_trajectories), ("psf", gen_psfs), ("boxes", gen_boxes),
-                     ("norm", gen_norm), ("fft", gen_fft), ("warper", gen_warper), ("jpeg", gen_jpeg)):
+                     ("norm", gen_norm), ("fft", gen_fft), ("warper", gen_warper), ("jpeg", gen_jpeg), ("coco", gen_coco_eval)):
         store = {}
         fn(ns, store)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)

@@ -45,5 +45,6 @@ def golden():
         blurdict = np.load(os.path.join(d, "blurdict.npz"))
         warper = np.load(os.path.join(d, "warper.npz"))
         jpeg = np.load(os.path.join(d, "jpeg.npz"))
+        coco = np.load(os.path.join(d, "coco.npz"))
         meta = json.load(open(os.path.join(d, "meta.json")))
     return G

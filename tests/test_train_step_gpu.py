@@ -38,6 +38,7 @@ def test_blurred_train_step_and_eval():
     assert not torch.equal(w0, m.backbone.body.conv1.weight.detach())
     out = evaluate(m, _loader(False), torch.device("cuda"), blurring_images=True, gpu_blur=True, expand_target_boxes=True)
     assert len(out["detections"]) == 4
+    assert out["coco_stats"] is not None and len(out["coco_stats"]) == 12 and all(-1.0 <= v <= 1.0 for v in out["coco_stats"])
 
 
 def test_engine_blur_equals_oracle_on_loader_batch():
