@@ -113,3 +113,29 @@ def test_random_trajectories_rasterise_bit_exact_on_device():
     p64, p16 = blur_ops.rasterize_psfs(torch.from_numpy(np.stack(trajs)), fracs, canvas=256, center=True)
     assert np.array_equal(p64.cpu().numpy().view(np.uint64), np.stack(want64).view(np.uint64))
     assert np.array_equal(p16.cpu().numpy().view(np.uint16), np.stack(want16).view(np.uint16))
+
+
+def test_compaction_general_path_dense_and_many_taps():
+    """PSFs that leave the fast path of the compaction kernel: more non-zeros than its LDS stage holds
+    (> 4096), a fully dense PSF, and weights that underflow in the division -- all against the oracle."""
+    from detectinblur_amd import blur_ops
+    rs = np.random.RandomState(99)
+    cases = []
+    a = np.zeros((128, 128), np.float16); idx = rs.choice(128 * 128, 5000, replace=False)
+    a.flat[idx] = (rs.random_sample(5000) + 0.05).astype(np.float16); cases.append(a)            # > STAGE_TAPS
+    cases.append((rs.random_sample((128, 128)) + 0.01).astype(np.float16))                       # dense
+    b = np.zeros((128, 128), np.float16); b[10, 10] = 60000.0; b[rs.randint(0, 128, 300), rs.randint(0, 128, 300)] = 1e-7
+    b[10, 10] = 60000.0; cases.append(b)                                                           # underflow: taps vanish
+    c = np.zeros((256, 256), np.float16); idx = rs.choice(256 * 256, 4097, replace=False)
+    c.flat[idx] = (rs.random_sample(4097) + 0.05).astype(np.float16); cases.append(c)            # 256 canvas, just over the stage
+    for psf in cases:
+        tabs = blur_ops.compact_psfs([torch.from_numpy(psf).cuda()], normalize=True)
+        rr, cc, ww = O.taps_of(O.normalize_psf(psf))
+        r, c_, w = tabs.taps(0)
+        assert tabs.header(0)[0] == len(rr)
+        assert np.array_equal(r.numpy(), rr) and np.array_equal(c_.numpy(), cc)
+        assert np.array_equal((w.numpy() & 0xffff).astype(np.uint16), ww.view(np.uint16))
+        if len(rr):
+            assert tuple(tabs.header(0)[1:5]) == (rr.min(), rr.max(), cc.min(), cc.max())
+        segs = tabs.segments(0)
+        assert segs[0][0] == 0 and segs[-1][1] == len(rr) and all(s[1] == t[0] for s, t in zip(segs, segs[1:]))
