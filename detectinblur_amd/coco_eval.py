@@ -39,7 +39,7 @@ def _iou_cpu(dt, gt, crowd):
 
 
 class CocoBoxEvaluator(object):
-    def __init__(self, ground_truth, device=None):
+    def __init__(self, ground_truth, device=None, cats=None):
         self.device = torch.device(device) if device is not None else None
         self.gt = {}
         for img, t in ground_truth.items():
@@ -50,9 +50,18 @@ class CocoBoxEvaluator(object):
                     if "area" in t else boxes[:, 2] * boxes[:, 3])
             self.gt[img] = dict(boxes=boxes, labels=np.asarray(torch.as_tensor(t["labels"]).cpu().numpy()).reshape(-1),
                                 crowd=crowd, area=area)
-        self.cats = sorted({int(c) for g in self.gt.values() for c in g["labels"]})
+        self.cats = sorted(cats) if cats is not None else sorted({int(c) for g in self.gt.values() for c in g["labels"]})
         self.results = {}      # (image, category) -> per-area-range records
         self.images = []
+
+    def set_ground_truth_xywh(self, img, boxes_xywh, labels, crowd, area):
+        """Ground truth of one image in COCO's own layout (bbox = x, y, w, h), installed or replaced just
+        before the image is evaluated: `engine.evaluate` edits the boxes of an image (expanded targets,
+        reference engine.py:325-342) before it scores it."""
+        self.gt[img] = dict(boxes=np.asarray(boxes_xywh, dtype=np.float64).reshape(-1, 4),
+                            labels=np.asarray(labels, dtype=np.int64).reshape(-1),
+                            crowd=np.asarray(crowd, dtype=np.int64).reshape(-1),
+                            area=np.asarray(area, dtype=np.float64).reshape(-1))
 
     # ---- per image ------------------------------------------------------------------------------------
     def _iou(self, dt, gt, crowd):
@@ -71,7 +80,9 @@ class CocoBoxEvaluator(object):
             scores = np.asarray(torch.as_tensor(d["scores"]).cpu().numpy(), dtype=np.float64).reshape(-1)
             labels = np.asarray(torch.as_tensor(d["labels"]).cpu().numpy()).reshape(-1)
             iou_all = self._iou(boxes, g["boxes"], g["crowd"])            # every detection x every ground truth
-            self.images.append(img)
+            if img not in self._seen():
+                self.images.append(img)
+                self._seen_set.add(img)
             for cat in self.cats:
                 di = np.nonzero(labels == cat)[0]
                 gi = np.nonzero(g["labels"] == cat)[0]
@@ -80,6 +91,11 @@ class CocoBoxEvaluator(object):
                 di = di[np.argsort(-scores[di], kind="mergesort")][:MAX_DETS[-1]]
                 self.results[(img, cat)] = self._match(iou_all[np.ix_(di, gi)], scores[di], boxes[di, 2] * boxes[di, 3],
                                                        g["crowd"][gi], g["area"][gi])
+
+    def _seen(self):
+        if not hasattr(self, "_seen_set") or len(self._seen_set) != len(self.images):
+            self._seen_set = set(self.images)
+        return self._seen_set
 
     @staticmethod
     def _match(ious, scores, dt_area, crowd, gt_area):
@@ -170,3 +186,62 @@ class CocoBoxEvaluator(object):
         self.stats = np.array([pick(1), pick(1, 0.5), pick(1, 0.75), pick(1, area=1), pick(1, area=2), pick(1, area=3),
                                pick(0, max_det=0), pick(0, max_det=1), pick(0), pick(0, area=1), pick(0, area=2), pick(0, area=3)])
         return self.stats
+
+
+_STAT_NAMES = ["AP @[ IoU=0.50:0.95 | area=   all | maxDets=100 ]", "AP @[ IoU=0.50      | area=   all | maxDets=100 ]",
+               "AP @[ IoU=0.75      | area=   all | maxDets=100 ]", "AP @[ IoU=0.50:0.95 | area= small | maxDets=100 ]",
+               "AP @[ IoU=0.50:0.95 | area=medium | maxDets=100 ]", "AP @[ IoU=0.50:0.95 | area= large | maxDets=100 ]",
+               "AR @[ IoU=0.50:0.95 | area=   all | maxDets=  1 ]", "AR @[ IoU=0.50:0.95 | area=   all | maxDets= 10 ]",
+               "AR @[ IoU=0.50:0.95 | area=   all | maxDets=100 ]", "AR @[ IoU=0.50:0.95 | area= small | maxDets=100 ]",
+               "AR @[ IoU=0.50:0.95 | area=medium | maxDets=100 ]", "AR @[ IoU=0.50:0.95 | area= large | maxDets=100 ]"]
+
+
+class CocoEvaluator(object):
+    """The reference's `coco_eval.CocoEvaluator` (coco_eval.py:20-77) for the box task, same surface:
+    `coco_gt` (a deep copy; `coco_gt.imgToAnns[image_id][k]["bbox"]` may be edited before the image is
+    scored), `update({image_id: {"boxes", "labels", "scores"}})`, `synchronize_between_processes()`,
+    `accumulate()`, `summarize()`, and `coco_eval["bbox"].stats` -- the 12 numbers reference train.py:350-387
+    and evaluate.py:249-259 log.  Underneath: CocoBoxEvaluator (IoU on the GPU when `device` is one)."""
+
+    def __init__(self, coco_gt, iou_types=("bbox",), device=None):
+        import copy
+        assert isinstance(iou_types, (list, tuple))
+        other = [t for t in iou_types if t != "bbox"]
+        if other:
+            raise NotImplementedError("iou types %s are outside the built path (Faster R-CNN: boxes only)" % other)
+        self.coco_gt = copy.deepcopy(coco_gt)
+        self.iou_types = list(iou_types)
+        cats = self.coco_gt.getCatIds() or sorted({a["category_id"] for a in self.coco_gt.dataset.get("annotations", [])})
+        self._ev = CocoBoxEvaluator({}, device=device, cats=cats)
+        self.coco_eval = {"bbox": self._ev}
+        self.img_ids = []
+
+    def update(self, predictions):
+        img_ids = [int(i) for i in np.unique(list(predictions.keys()))]
+        self.img_ids.extend(img_ids)
+        for img in img_ids:
+            anns = self.coco_gt.imgToAnns.get(img, [])
+            self._ev.set_ground_truth_xywh(img, [a["bbox"] for a in anns], [a["category_id"] for a in anns],
+                                           [a.get("ignore", 0) or a["iscrowd"] for a in anns], [a["area"] for a in anns])
+        self._ev.update({int(k): v for k, v in predictions.items()})
+
+    def synchronize_between_processes(self):
+        """Every rank ends up with every rank's per-image records, images unique and ascending by id (the
+        reference's np.unique merge, coco_eval.py:283-303).  The collective is entered unconditionally."""
+        from . import utils
+        merged = {}
+        for part in utils.all_gather(self._ev.results):
+            merged.update(part)
+        self._ev.results = merged
+        self._ev.images = sorted({img for img, _ in merged} | set(self._ev.images))
+        self.img_ids = list(self._ev.images)
+
+    def accumulate(self):
+        self._ev.accumulate()
+
+    def summarize(self):
+        print("IoU metric: bbox")
+        stats = self._ev.summarize()
+        for name, v in zip(_STAT_NAMES, stats):
+            print(" Average %s (%s) %s = %0.3f" % ("Precision" if name.startswith("AP") else "Recall   ", name[:2], name[3:], v))
+        return stats

@@ -1,11 +1,132 @@
-"""Data feed with the reference's item layout `(image, target, blur_dict)` (reference
-coco_utils.py:231-240).  COCO itself (torchvision.datasets.CocoDetection + pycocotools) is not
-available offline, so the COCO-shaped synthetic dataset below stands in for it: same tensors, same
-target keys (`boxes` xyxy float32, `labels` int64, `image_id`, `area`, `iscrowd`; coco_utils.py:90-102).
+"""Data feed with the reference's item layout `(image, target, blur_dict)` (reference coco_utils.py).
+
+Two datasets, one layout:
+  * `CocoDetection` -- a real COCO tree (`{root}/train2017`, `{root}/annotations/instances_train2017.json`, ...)
+    read with `json` + PIL only: neither torchvision.datasets.CocoDetection nor pycocotools is needed for the
+    box path (reference coco_utils.py:231-271).  `ConvertCocoPolysToMask` turns the raw annotations into the
+    target dict of reference coco_utils.py:51-104 (`boxes` xyxy float32 clipped to the image, `labels` int64,
+    `image_id`, `area`, `iscrowd`); segmentation masks need pycocotools' RLE decoder and are NOT produced
+    (Faster R-CNN never reads them).  Training drops images without a usable annotation (:106-147).
+  * `SyntheticCocoDetection` -- COCO-shaped random images and boxes, the offline stand-in (`--synthetic`).
+`get_coco_api_from_dataset` (reference :218-226) hands `engine.evaluate` the ground truth as a `CocoGT`
+(the few fields of pycocotools' COCO object the evaluation reads: `dataset`, `imgToAnns`, `imgs`).
 """
+import json
+import os
+from collections import defaultdict
+
 import numpy as np
 import torch
 import torch.utils.data
+
+from . import transforms as T
+
+
+class CocoGT(object):
+    """The slice of pycocotools.coco.COCO the evaluation path touches (reference coco_eval.py:24-29,
+    engine.py:325-342): `dataset`, `imgs`, `imgToAnns` (lists of the SAME annotation dicts, so in-place
+    edits of `bbox` are seen by the evaluator), `getAnnIds` / `loadAnns` / `getCatIds`."""
+
+    def __init__(self, dataset=None):
+        self.dataset = dataset if dataset is not None else {"images": [], "annotations": [], "categories": []}
+        self.createIndex()
+
+    def createIndex(self):
+        self.anns, self.imgs, self.cats = {}, {}, {}
+        self.imgToAnns = defaultdict(list)
+        for ann in self.dataset.get("annotations", []):
+            self.imgToAnns[ann["image_id"]].append(ann)
+            self.anns[ann["id"]] = ann
+        for img in self.dataset.get("images", []):
+            self.imgs[img["id"]] = img
+        for cat in self.dataset.get("categories", []):
+            self.cats[cat["id"]] = cat
+
+    def getAnnIds(self, imgIds, iscrowd=None):
+        ids = imgIds if isinstance(imgIds, (list, tuple)) else [imgIds]
+        return [a["id"] for i in ids for a in self.imgToAnns.get(i, []) if iscrowd is None or a["iscrowd"] == iscrowd]
+
+    def loadAnns(self, ids):
+        return [self.anns[i] for i in ids]
+
+    def getCatIds(self):
+        return sorted(self.cats)
+
+    def getImgIds(self):
+        return sorted(self.imgs)
+
+
+class ConvertCocoPolysToMask(object):
+    """reference coco_utils.py:51-104, box path: crowd annotations are dropped from the target, xywh -> xyxy,
+    clamped to the image, boxes without positive extent dropped; `area` / `iscrowd` keep one entry per
+    non-crowd annotation (NOT filtered by `keep`, as in the reference)."""
+
+    def __call__(self, image, target, blur_dict=None):
+        blur_dict = {} if blur_dict is None else blur_dict
+        w, h = image.size
+        image_id = torch.tensor([target["image_id"]])
+        anno = [obj for obj in target["annotations"] if obj["iscrowd"] == 0]
+        boxes = torch.as_tensor([obj["bbox"] for obj in anno], dtype=torch.float32).reshape(-1, 4)
+        boxes[:, 2:] += boxes[:, :2]
+        boxes[:, 0::2].clamp_(min=0, max=w)
+        boxes[:, 1::2].clamp_(min=0, max=h)
+        classes = torch.tensor([obj["category_id"] for obj in anno], dtype=torch.int64)
+        keep = (boxes[:, 3] > boxes[:, 1]) & (boxes[:, 2] > boxes[:, 0])
+        out = {"boxes": boxes[keep], "labels": classes[keep], "image_id": image_id,
+               "area": torch.tensor([obj["area"] for obj in anno]), "iscrowd": torch.tensor([obj["iscrowd"] for obj in anno])}
+        return image, out, blur_dict
+
+
+class CocoDetection(torch.utils.data.Dataset):
+    """torchvision.datasets.CocoDetection + the reference's subclass (coco_utils.py:231-240) without either
+    dependency: item = `(PIL RGB image, {"image_id", "annotations"}, {})` run through `transforms`."""
+
+    def __init__(self, img_folder, ann_file, transforms=None):
+        self.root = img_folder
+        with open(ann_file) as f:
+            self.coco = CocoGT(json.load(f))
+        self.ids = list(sorted(self.coco.imgs.keys()))
+        self._transforms = transforms
+        self._epoch_number = 0
+
+    def __len__(self):
+        return len(self.ids)
+
+    def _load_image(self, image_id):
+        from PIL import Image
+        return Image.open(os.path.join(self.root, self.coco.imgs[image_id]["file_name"])).convert("RGB")
+
+    def __getitem__(self, idx):
+        image_id = self.ids[idx]
+        img = self._load_image(image_id)
+        target = dict(image_id=image_id, annotations=self.coco.loadAnns(self.coco.getAnnIds(image_id)))
+        blur_dict = {}
+        if self._transforms is not None:
+            img, target, blur_dict = self._transforms(img, target)
+        return img, target, blur_dict
+
+
+def _has_valid_annotation(anno):
+    """reference coco_utils.py:106-132."""
+    if len(anno) == 0:
+        return False
+    if all(any(o <= 1 for o in obj["bbox"][2:]) for obj in anno):          # every box (close to) empty
+        return False
+    if "keypoints" not in anno[0]:
+        return True
+    return sum(sum(1 for v in ann["keypoints"][2::3] if v > 0) for ann in anno) >= 10
+
+
+def _coco_remove_images_without_annotations(dataset, cat_list=None):
+    """reference coco_utils.py:106-147: a Subset of the images that carry at least one usable annotation."""
+    ids = []
+    for ds_idx, img_id in enumerate(dataset.ids):
+        anno = dataset.coco.loadAnns(dataset.coco.getAnnIds(img_id, iscrowd=None))
+        if cat_list:
+            anno = [obj for obj in anno if obj["category_id"] in cat_list]
+        if _has_valid_annotation(anno):
+            ids.append(ds_idx)
+    return torch.utils.data.Subset(dataset, ids)
 
 
 class SyntheticCocoDetection(torch.utils.data.Dataset):
@@ -18,14 +139,13 @@ class SyntheticCocoDetection(torch.utils.data.Dataset):
         self.num_images, self.size, self.boxes_per_image, self.num_classes = num_images, size, boxes_per_image, num_classes
         self._transforms, self.seed, self.as_tensor = transforms, seed, as_tensor
         self.epoch_number = None
+        self._epoch_number = 0
 
     def __len__(self):
         return self.num_images
 
-    def __getitem__(self, idx):
+    def _target(self, idx, g):
         H, W = self.size
-        g = torch.Generator().manual_seed(self.seed + idx)
-        img = torch.rand(3, H, W, generator=g)
         n = self.boxes_per_image
         x1 = torch.rand(n, generator=g) * (W - 34)
         y1 = torch.rand(n, generator=g) * (H - 34)
@@ -33,8 +153,14 @@ class SyntheticCocoDetection(torch.utils.data.Dataset):
         h = 32 + torch.rand(n, generator=g) * (400 - 32)
         boxes = torch.stack([x1, y1, torch.minimum(x1 + w, torch.tensor(float(W))), torch.minimum(y1 + h, torch.tensor(float(H)))], 1)
         labels = torch.randint(1, self.num_classes, (n,), generator=g)
-        target = {"boxes": boxes, "labels": labels, "image_id": torch.tensor([idx]),
-                  "area": (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), "iscrowd": torch.zeros(n, dtype=torch.int64)}
+        return {"boxes": boxes, "labels": labels, "image_id": torch.tensor([idx]),
+                "area": (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), "iscrowd": torch.zeros(n, dtype=torch.int64)}
+
+    def __getitem__(self, idx):
+        H, W = self.size
+        g = torch.Generator().manual_seed(self.seed + idx)
+        img = torch.rand(3, H, W, generator=g)
+        target = self._target(idx, g)
         if not self.as_tensor:   # PIL image, as CocoDetection hands to the transforms (needed by --cpu_blur)
             from PIL import Image
             img = Image.fromarray((img.permute(1, 2, 0).numpy() * 255).astype(np.uint8))
@@ -43,11 +169,76 @@ class SyntheticCocoDetection(torch.utils.data.Dataset):
             img, target, blur_dict = self._transforms(img, target, blur_dict)
         return img, target, blur_dict
 
+    def annotations(self, idx):
+        """The target of item idx without rendering the image or running the transforms (same generator
+        stream: the image's 3*H*W draws are skipped by drawing them)."""
+        g = torch.Generator().manual_seed(self.seed + idx)
+        torch.rand(3, self.size[0], self.size[1], generator=g)
+        return self._target(idx, g)
+
+
+def convert_to_coco_api(ds):
+    """reference coco_utils.py:150-215 for datasets that are not a CocoDetection: one pass over the items'
+    targets -> COCO-style ground truth (annotation ids from 1, bbox as xywh)."""
+    dataset = {"images": [], "categories": [], "annotations": []}
+    categories, ann_id = set(), 1
+    for img_idx in range(len(ds)):
+        if hasattr(ds, "annotations"):
+            targets, height, width = ds.annotations(img_idx), ds.size[0], ds.size[1]
+        else:
+            img, targets, _ = ds[img_idx]
+            height, width = (img.height, img.width) if hasattr(img, "height") else (img.shape[-2], img.shape[-1])
+        image_id = int(targets["image_id"].item())
+        dataset["images"].append({"id": image_id, "height": height, "width": width})
+        bboxes = targets["boxes"].clone()
+        bboxes[:, 2:] -= bboxes[:, :2]
+        bboxes = bboxes.tolist()
+        labels, areas, iscrowd = targets["labels"].tolist(), targets["area"].tolist(), targets["iscrowd"].tolist()
+        for i in range(len(bboxes)):
+            dataset["annotations"].append({"image_id": image_id, "bbox": bboxes[i], "category_id": labels[i], "area": areas[i],
+                                           "iscrowd": iscrowd[i], "id": ann_id})
+            categories.add(labels[i])
+            ann_id += 1
+    dataset["categories"] = [{"id": i} for i in sorted(categories)]
+    return CocoGT(dataset)
+
+
+def get_coco_api_from_dataset(dataset):
+    """reference coco_utils.py:218-226."""
+    for _ in range(10):
+        if isinstance(dataset, CocoDetection):
+            break
+        if isinstance(dataset, torch.utils.data.Subset):
+            dataset = dataset.dataset
+    if isinstance(dataset, CocoDetection):
+        return dataset.coco
+    return convert_to_coco_api(dataset)
+
 
 def get_coco(root, image_set, transforms, mode="instances", synthetic=None):
-    """(dataset, num_classes).  `root` is ignored when `synthetic` (a dict of SyntheticCocoDetection
-    kwargs) is given; a real COCO tree needs torchvision + pycocotools, which this image lacks."""
-    if synthetic is None:
-        raise RuntimeError("COCO needs torchvision.datasets.CocoDetection and pycocotools (not installed); "
-                           "pass --synthetic to train/evaluate on COCO-shaped synthetic data")
-    return SyntheticCocoDetection(transforms=transforms, **synthetic), 91
+    """reference coco_utils.py:243-271.  Returns `(dataset, num_classes)` (the reference's train.get_dataset
+    adds the 91; folded in here).  With `synthetic` (a dict of SyntheticCocoDetection kwargs) `root` is ignored."""
+    if synthetic is not None:
+        return SyntheticCocoDetection(transforms=transforms, **synthetic), 91
+    if root is None:
+        raise RuntimeError("no --data_path given: point it at a COCO tree (train2017/, val2017/, annotations/) "
+                           "or pass --synthetic for COCO-shaped synthetic data")
+    anno_file_template = "{}_{}2017.json"
+    PATHS = {"train": ("train2017", os.path.join("annotations", anno_file_template.format(mode, "train"))),
+             "val": ("val2017", os.path.join("annotations", anno_file_template.format(mode, "val")))}
+    t = [ConvertCocoPolysToMask()]
+    if transforms is not None:
+        t.append(transforms)
+    img_folder, ann_file = PATHS[image_set]
+    img_folder, ann_file = os.path.join(root, img_folder), os.path.join(root, ann_file)
+    if not os.path.isfile(ann_file):
+        raise FileNotFoundError("COCO annotation file %s not found (pass --synthetic to run without a dataset)" % ann_file)
+    dataset = CocoDetection(img_folder, ann_file, transforms=T.Compose(t))
+    if image_set == "train":
+        dataset = _coco_remove_images_without_annotations(dataset)
+    return dataset, 91
+
+
+def get_coco_kp(root, image_set, transforms):
+    return get_coco(root, image_set, transforms, mode="person_keypoints")
+

@@ -5,10 +5,11 @@ What one training step does, in order (reference engine.py:74-158):
   H2D as fp16 -> blur_image_list (HIP) -> expand_targets (HIP) -> .float() -> per-image norm statistics
   -> model(images, targets, newMeans, newSTDs) -> loss all-reduce for logging -> backward (DDP all-reduce
   over RCCL overlapped with it) -> SGD step -> warm-up LR step.
-Differences from the reference are confined to mechanics: host->device copies are pinned + non-blocking,
-the blur needs no host synchronisation, and the logged loss is fetched with one `.item()` per step.
-COCO mAP (pycocotools, `coco_eval.py`) is outside the built path; `evaluate`
-returns the raw detections plus timing instead of a CocoEvaluator.
+Differences from the reference are confined to mechanics: images cross PCIe as the loader's pinned fp32 and
+are converted to Half on the device (same round-to-nearest-even as `.half()` on the host), the blur needs no
+host synchronisation, and the logged loss is fetched with one `.item()` per step.
+`evaluate` returns the reference's `CocoEvaluator` surface (`.coco_eval["bbox"].stats`) computed by the
+in-repo `coco_eval.py` (no pycocotools), see EvaluationResult.
 """
 import math
 import sys
@@ -21,15 +22,42 @@ from .models import blur_functions, net_transforms
 
 
 def _to_device(images_CPU, targets, blur_dicts, device, blurring):
-    """reference engine.py:79-98: images as Half, PSFs via torch.HalfTensor(ndarray)."""
-    images_GPU = [image.half().to(device, non_blocking=True) for image in images_CPU]
+    """reference engine.py:79-98: images as Half, PSFs via torch.HalfTensor(ndarray).
+    On a GPU the fp32 tensor the DataLoader pinned is uploaded as is (a true asynchronous copy) and rounded to
+    Half on the device -- the same round-to-nearest-even as `.half()` on the host, without the pageable
+    intermediate that made the copy host-synchronous."""
+    if device.type == "cuda":
+        images_GPU = [image.to(device, non_blocking=True).half() for image in images_CPU]
+    else:
+        images_GPU = [image.half() for image in images_CPU]
     targets_GPU = [{k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in t.items()} for t in targets]
     psfs_GPU = thetas = l1 = l2 = None
     if blurring:
-        psfs_GPU = [torch.HalfTensor(bd["psf"]).to(device, non_blocking=True) for bd in blur_dicts]
-        thetas = torch.tensor([bd["theta_rad"] for bd in blur_dicts], dtype=torch.float16, device=device)
-        l1 = torch.tensor([bd["scale_factor_lambda1"] for bd in blur_dicts], dtype=torch.float16, device=device)
-        l2 = torch.tensor([bd["scale_factor_lambda2"] for bd in blur_dicts], dtype=torch.float16, device=device)
+        cuda = device.type == "cuda"
+        # PSFs: torch.HalfTensor(ndarray) (float64 -> float32 -> float16) into ONE pinned staging block per
+        # batch and one asynchronous copy; the list entries are views of it.  Entries of another shape (the
+        # 1-element [0] of a not-blurred image, reference transforms.py:455) travel on their own.
+        halves = [torch.HalfTensor(bd["psf"]) for bd in blur_dicts]
+        shapes = {tuple(h.shape) for h in halves if h.dim() == 2}
+        psfs_GPU = [None] * len(halves)
+        if len(shapes) == 1 and cuda:
+            shp = next(iter(shapes))
+            sel = [i for i, h in enumerate(halves) if tuple(h.shape) == shp]
+            stage = torch.empty((len(sel),) + shp, dtype=torch.float16, pin_memory=True)
+            for k, i in enumerate(sel):
+                stage[k].copy_(halves[i])
+            block = stage.to(device, non_blocking=True)
+            for k, i in enumerate(sel):
+                psfs_GPU[i] = block[k]
+        for i, h in enumerate(halves):
+            if psfs_GPU[i] is None:
+                psfs_GPU[i] = h.to(device, non_blocking=True)
+        # theta / lambda1 / lambda2: one [3, B] pinned tensor, one copy
+        scal = torch.tensor([[bd["theta_rad"] for bd in blur_dicts], [bd["scale_factor_lambda1"] for bd in blur_dicts],
+                             [bd["scale_factor_lambda2"] for bd in blur_dicts]], dtype=torch.float16)
+        if cuda:
+            scal = scal.pin_memory().to(device, non_blocking=True)
+        thetas, l1, l2 = scal[0], scal[1], scal[2]
     return images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2
 
 
@@ -121,14 +149,42 @@ def get_network_index_to_use_blur_estimator_LEHE(blur_estimation, model_indices)
     return model_indices[k if k in (1, 2, 3) else 0]
 
 
+class EvaluationResult(object):
+    """What `evaluate` returns: the reference's `CocoEvaluator` surface (`.coco_eval["bbox"].stats`, `.coco_gt`,
+    `.img_ids`; reference engine.py:416, train.py:350-387) plus the raw material of the run as attributes and,
+    for callers that index it, as keys: "detections" {image_id: {boxes, labels, scores}}, "targets"
+    {image_id: xywh boxes as written into the ground truth}, "routes" [model index per batch], "meters",
+    "coco_stats" (the 12 numbers, or None when the dataset carries no annotations)."""
+
+    def __init__(self, coco_evaluator, **extra):
+        self._ce = coco_evaluator
+        self._extra = extra
+        for k, v in extra.items():
+            setattr(self, k, v)
+
+    def __getattr__(self, name):            # CocoEvaluator surface: coco_eval, coco_gt, img_ids, iou_types, ...
+        return getattr(self.__dict__["_ce"], name)
+
+    def __getitem__(self, key):
+        return self._extra[key]
+
+    def __contains__(self, key):
+        return key in self._extra
+
+    def keys(self):
+        return self._extra.keys()
+
+
 @torch.no_grad()
 def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None, vanilla_eval=False, blurring_images=False,
              gpu_blur=False, expand_target_boxes=False, deblur_first=False, deblurer=None, use_custom_image_norm=False,
              use_ensemble=False, ensemble_models=None, blur_estimator=None, add_noise=False, noise_level=0.001, add_block=False,
-             add_jpeg_artifact=False, image_output_folder=None, LEHE=False):
-    """Runs the detector (or the routed ensemble) over the loader.  Returns
-    {"detections": {image_id: {boxes, labels, scores}}, "targets": {image_id: expanded boxes},
-     "routes": [model index per batch], "meters": MetricLogger}."""
+             add_jpeg_artifact=False, image_output_folder=None, LEHE=False, epoch_number=None):
+    """reference engine.py:220-416.  Runs the detector (or the routed ensemble) over the loader, scores the
+    detections against the dataset's COCO ground truth (boxes replaced by the expanded ones under
+    `expand_target_boxes`, :325-342) and returns the evaluator (see EvaluationResult)."""
+    from .coco_eval import CocoEvaluator
+    from .coco_utils import get_coco_api_from_dataset
     if deblur_first:
         raise NotImplementedError("--deblur_first is outside the built path (SURVEY.md section 2)")
     jpeg_compressor = None
@@ -147,8 +203,10 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
     else:
         model.eval()
     metric_logger = utils.MetricLogger(delimiter="  ")
-    detections, gt_boxes, gt_full, routes = {}, {}, {}, []
-    count = 0
+    coco = get_coco_api_from_dataset(data_loader.dataset)                # reference :271-273
+    coco_evaluator = CocoEvaluator(coco, ["bbox"], device=device if device.type == "cuda" else None)
+    detections, gt_boxes, routes = {}, {}, []
+    count = faulty_boxes = total_boxes = 0
     for images_CPU, targets_CPU, blur_dicts in metric_logger.log_every(data_loader, 100, "Test:"):
         if device.type == "cuda":
             torch.cuda.synchronize()
@@ -160,6 +218,17 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                                            jpeg_compressor=jpeg_compressor)
         if expand_target_boxes and blurring_images:
             targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU)
+            # the expanded boxes replace the ground truth's, annotation k <- target box k (reference :325-342,
+            # index-wise: where the target dropped a crowd / degenerate annotation the tail keeps its box)
+            for target in targets_GPU:
+                boxes = utils.convert_to_xywh(target["boxes"]).cpu().numpy().tolist()
+                anns = coco_evaluator.coco_gt.imgToAnns[int(target["image_id"].item())]
+                for k, ann in enumerate(anns):
+                    total_boxes += 1
+                    if k < len(boxes):
+                        ann["bbox"] = boxes[k]
+                    else:
+                        faulty_boxes += 1
         images_GPU = [image.float().to(device) for image in images_GPU]   # JPEG artefacts come back on the host (transforms.py:492)
         norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 
@@ -179,48 +248,26 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
             outputs = model(images_GPU, killWarp=True, newMeans=norm_means, newSTDs=norm_stds)
         outputs = [{k: v.to("cpu") for k, v in t.items()} for t in outputs]
         model_time = time.time() - model_time
+        res = {}
         for t, o in zip(targets_GPU, outputs):
             image_id = int(t["image_id"]) if "image_id" in t else count
+            res[image_id] = o
             detections[image_id] = o
-            gt_boxes[image_id] = utils.convert_to_xywh(t["boxes"]).cpu()   # what the reference writes into coco_gt (:325-342)
-            if "labels" in t:
-                # annotations as COCOeval sees them: the (expanded) box replaces bbox, area / iscrowd stay (:325-342)
-                gt_full[image_id] = {k: t[k].detach().cpu() for k in ("boxes", "labels", "area", "iscrowd") if k in t}
-        metric_logger.update(model_time=model_time)
+            gt_boxes[image_id] = utils.convert_to_xywh(t["boxes"]).cpu()
+        evaluator_time = time.time()
+        coco_evaluator.update(res)                                       # reference :388-392
+        evaluator_time = time.time() - evaluator_time
+        metric_logger.update(model_time=model_time, evaluator_time=evaluator_time)
         count += 1
         if early_stop is not None and count > early_stop:
             break
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
+    print("Number of Faulty boxes: " + str(faulty_boxes) + " Total number of boxes: " + str(total_boxes))
+    coco_evaluator.synchronize_between_processes()                       # a collective on every rank, shards empty or not
+    coco_evaluator.accumulate()
+    stats = coco_evaluator.summarize() if utils.is_main_process() else coco_evaluator.coco_eval["bbox"].summarize()
     torch.set_num_threads(n_threads)
-    coco_stats = None
-    if gt_full:                                                          # reference :410-414 (CocoEvaluator)
-        coco_stats = coco_box_stats(detections, gt_full, device)
-    return {"detections": detections, "targets": gt_boxes, "routes": routes, "meters": metric_logger, "coco_stats": coco_stats}
-
-
-_STAT_NAMES = ["AP @[ IoU=0.50:0.95 | area=   all | maxDets=100 ]", "AP @[ IoU=0.50      | area=   all | maxDets=100 ]",
-               "AP @[ IoU=0.75      | area=   all | maxDets=100 ]", "AP @[ IoU=0.50:0.95 | area= small | maxDets=100 ]",
-               "AP @[ IoU=0.50:0.95 | area=medium | maxDets=100 ]", "AP @[ IoU=0.50:0.95 | area= large | maxDets=100 ]",
-               "AR @[ IoU=0.50:0.95 | area=   all | maxDets=  1 ]", "AR @[ IoU=0.50:0.95 | area=   all | maxDets= 10 ]",
-               "AR @[ IoU=0.50:0.95 | area=   all | maxDets=100 ]", "AR @[ IoU=0.50:0.95 | area= small | maxDets=100 ]",
-               "AR @[ IoU=0.50:0.95 | area=medium | maxDets=100 ]", "AR @[ IoU=0.50:0.95 | area= large | maxDets=100 ]"]
-
-
-def coco_box_stats(detections, ground_truth, device):
-    """The 12 COCO box statistics over every rank's images (detections / ground truth are gathered first);
-    the IoU runs on `device` when it is a GPU (coco_eval.CocoBoxEvaluator)."""
-    from .coco_eval import CocoBoxEvaluator
-    if utils.is_dist_avail_and_initialized():
-        merged_d, merged_g = {}, {}
-        for d, g in utils.all_gather((detections, ground_truth)):
-            merged_d.update(d)
-            merged_g.update(g)
-        detections, ground_truth = merged_d, merged_g
-    ev = CocoBoxEvaluator(ground_truth, device=device if device.type == "cuda" else None)
-    ev.update({k: v for k, v in detections.items() if k in ground_truth})
-    stats = ev.summarize()
-    if utils.is_main_process():
-        for name, v in zip(_STAT_NAMES, stats):
-            print(" Average %s (%s) %s = %0.3f" % ("Precision" if name.startswith("AP") else "Recall   ", name[:2], name[3:], v))
-    return stats
+    has_gt = len(coco_evaluator.coco_gt.dataset.get("annotations", [])) > 0
+    return EvaluationResult(coco_evaluator, detections=detections, targets=gt_boxes, routes=routes, meters=metric_logger,
+                            coco_stats=stats if has_gt else None)

@@ -1,8 +1,11 @@
 """`FasterRCNN` / `fasterrcnn_resnet50_fpn` with the reference's constructor surface and defaults
 (reference models/faster_rcnn.py:144-243, 301-373).  No weights are downloaded here (no network):
-`pretrained` / `pretrained_backbone` raise; random initialisation trains every backbone layer, as in
-the reference when neither is set (:361-363).
+`pretrained` / `pretrained_backbone` load the files the reference would have downloaded when they already
+sit in a local cache (`find_pretrained`), and raise otherwise; random initialisation trains every backbone
+layer, as in the reference when neither is set (:361-363).
 """
+import os
+
 import torch
 from .backbone import resnet_fpn_backbone
 from .detector_ops import MultiScaleRoIAlign
@@ -57,15 +60,54 @@ class FasterRCNN(GeneralizedRCNN):
         super().__init__(backbone, rpn, roi_heads, transform, warp_internally)
 
 
+# what the reference downloads (models/faster_rcnn.py:295-298; torchvision.models.resnet.model_urls['resnet50'])
+PRETRAINED_FILES = {"fasterrcnn_resnet50_fpn_coco": ("fasterrcnn_resnet50_fpn_coco-258fb6c6.pth",),
+                    "resnet50": ("resnet50-19c8e357.pth", "resnet50-0676ba61.pth")}
+
+
+def find_pretrained(kind):
+    """Path of a locally cached checkpoint of `kind`, or None.  Searched: $DIB_WEIGHTS_DIR,
+    $TORCH_HOME/hub/checkpoints, ~/.cache/torch/hub/checkpoints, ./weights."""
+    dirs = [os.environ.get("DIB_WEIGHTS_DIR"),
+            os.path.join(os.environ.get("TORCH_HOME", os.path.join(os.path.expanduser("~"), ".cache", "torch")), "hub", "checkpoints"),
+            "weights"]
+    for d in dirs:
+        for name in PRETRAINED_FILES[kind]:
+            if d and os.path.isfile(os.path.join(d, name)):
+                return os.path.join(d, name)
+    return None
+
+
 def fasterrcnn_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pretrained_backbone=True,
                             trainable_backbone_layers=3, channels_last=True, **kwargs):
+    """reference models/faster_rcnn.py:301-373.  `pretrained_backbone="auto"`: ImageNet trunk if a cached
+    file exists, random initialisation (with a note) otherwise -- what `train.py` asks for, since the
+    reference's default (True) means "download"."""
     assert 0 <= trainable_backbone_layers <= 5
-    if pretrained or pretrained_backbone:
-        raise RuntimeError("pretrained weights cannot be downloaded here (no network); build with pretrained=False, "
-                           "pretrained_backbone=False and load a state_dict (torchvision key layout is kept)")
-    trainable_backbone_layers = 5      # nothing is frozen without pretrained weights (reference :361-363)
+    full = find_pretrained("fasterrcnn_resnet50_fpn_coco") if pretrained else None
+    if pretrained and full is None:
+        raise RuntimeError("pretrained=True: %s is not in $DIB_WEIGHTS_DIR / the torch hub cache / ./weights and "
+                           "cannot be downloaded here (no network)" % PRETRAINED_FILES["fasterrcnn_resnet50_fpn_coco"][0])
+    trunk = None
+    if pretrained:
+        pretrained_backbone = False      # no need for the trunk file when the full model is loaded (reference :364-366)
+    elif pretrained_backbone:
+        trunk = find_pretrained("resnet50")
+        if trunk is None:
+            if pretrained_backbone != "auto":
+                raise RuntimeError("pretrained_backbone=True: none of %s is cached locally and there is no network; pass "
+                                   "pretrained_backbone=False (random init)" % (PRETRAINED_FILES["resnet50"],))
+            print("No cached ImageNet ResNet-50 found: the trunk starts from random weights, every layer trainable.")
+            pretrained_backbone = False
+    if not (pretrained or pretrained_backbone):
+        trainable_backbone_layers = 5      # nothing is frozen without pretrained weights (reference :361-363)
     backbone = resnet_fpn_backbone("resnet50", False, trainable_layers=trainable_backbone_layers)
+    if trunk is not None:
+        sd = torch.load(trunk, map_location="cpu", weights_only=True)
+        backbone.body.load_state_dict({k: v for k, v in sd.items() if not k.startswith("fc.")}, strict=False)
     model = FasterRCNN(backbone, num_classes, **kwargs)
+    if full is not None:
+        model.load_state_dict(torch.load(full, map_location="cpu", weights_only=True))
     if channels_last:
         # MI355X: MIOpen's fp32 implicit-GEMM convolutions are NHWC kernels (planar tensors pay a
         # transpose around each), and the NHWC RoIAlign issues one atomic per 64 contiguous channels.

@@ -82,21 +82,28 @@ def test_train_cli_with_stored_psfs_end_to_end(tmp_path, capsys):
         "--synthetic", "--synthetic_images", "4", "--synthetic_size", "160", "224", "--blur_train", "--gpu_blur",
         "--use_stored_psfs", "--stored_psf_directory", dest + "psfs", "--stored_psf_count", "2", "--param_index", "1",
         "--low_exposure", "--expand_target_boxes", "--use_custom_image_norm", "-b", "2", "--epochs", "1", "--early_stop", "2",
-        "--lr", "0.002", "--print_freq", "1", "--output_dir", out])
+        "--lr", "0.002", "--print_freq", "1", "--output_dir", out, "--tensorboard_path", str(tmp_path / "tb")])
     train.main(args)
     text = capsys.readouterr().out
     assert "loss_classifier" in text and "nan" not in text.lower().split("namespace")[-1]
 
 
-def test_evaluate_cli_ensemble_sweep_end_to_end(capsys):
+def test_evaluate_cli_ensemble_sweep_end_to_end(capsys, tmp_path):
     """BASELINE configs[4] in miniature: the (type x exposure) sweep through 4 detectors + estimator."""
     from detectinblur_amd import evaluate as E
     args = E.build_parser().parse_args(["--synthetic", "--synthetic_images", "2", "--synthetic_size", "160", "224", "--use_ensemble",
                                       "--LEHE", "--use_blur_estimator", "--blur_eval", "--gpu_blur", "--expand_target_boxes",
-                                      "--early_stop", "1"])
-    E.main(args)
+                                      "--early_stop", "1", "--tensorboard_path", str(tmp_path / "tb")])
+    res = E.main(args)
     text = capsys.readouterr().out
     assert text.count("routes") == 15           # 3 blur types x 5 exposures
+    assert len(res) == 15 and res["P1E0"].coco_eval["bbox"].stats.shape == (12,)
+    from detectinblur_amd import tb_writer
+    import os
+    ev = os.path.join(str(tmp_path / "tb"), os.listdir(str(tmp_path / "tb"))[0])
+    if not ev.endswith(".v2"):
+        tags = {(t, s) for t, s, _ in tb_writer.read_scalars(ev)}
+        assert ("P1/AccuraciesSweep", 1) in tags and ("P3/recall", 5) in tags      # reference evaluate.py:358-368
 
 
 def test_train_cli_with_full_corruption_chain(tmp_path, capsys):
@@ -105,7 +112,8 @@ def test_train_cli_with_full_corruption_chain(tmp_path, capsys):
     args = train.build_parser().parse_args([
         "--synthetic", "--synthetic_images", "4", "--synthetic_size", "160", "224", "--blur_train", "--gpu_blur",
         "--param_index", "2", "--high_exposure", "--expand_target_boxes", "--add_noise", "--add_block", "--add_jpeg_artefacts",
-        "-b", "2", "--epochs", "1", "--early_stop", "2", "--lr", "0.002", "--print_freq", "1", "--output_dir", str(tmp_path / "run")])
+        "-b", "2", "--epochs", "1", "--early_stop", "2", "--lr", "0.002", "--print_freq", "1", "--output_dir", str(tmp_path / "run"),
+        "--tensorboard_path", str(tmp_path / "tb")])
     train.main(args)
     text = capsys.readouterr().out
     assert "loss_classifier" in text and "Loss is" not in text
