@@ -39,7 +39,6 @@ class TapTables:
         self.words = table_words(K)
         if self.words == 0:
             raise ValueError("PSF must be 128 or 256 wide, got %d" % K)
-        # `count` tables + the scheduler trailer (zeroed by dib_psf_compact)
         self.buf = torch.empty(_lib.lib().dib_tap_tables_bytes(K, count) // 4, dtype=torch.int32, device=device)
 
     def ptr(self, i=0):

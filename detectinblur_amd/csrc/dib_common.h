@@ -28,8 +28,6 @@ __host__ __device__ inline int table_segs_off(int K) { return table_taps_off(K) 
 __host__ __device__ inline int table_ltaps_off(int K) { return table_segs_off(K) + 4 * K * K; }
 __host__ __device__ inline int table_words(int K) { return table_ltaps_off(K) + K * K + 8; }
 
-constexpr int SCHED_WORDS = 256;  // trailer behind the last table: 16 tile-queue words per blur launch
-
 // ---- padding modes of manual_blur (models/blur_functions.py:28-31, :55-58) ---------------
 enum PadMode { PAD_REFLECT = 0, PAD_ZERO = 1, PAD_REPLICATE = 2 };
 
@@ -75,7 +73,7 @@ struct ImageDesc {
   int C, H, W;
   int table;       // index into the table array
   int tile_begin;  // first flattened tile id of this image in the launch
-  int tiles_x;     // 256-px-wide tiles per row
+  int tiles_x;     // tiles per row (128 or 256 px wide, by the shape of the launch)
   int tiles_y;     // 32-row tiles per channel
 };
 

@@ -155,8 +155,6 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   const T *p = reinterpret_cast<const T *>(ptrs.p[blockIdx.x]) + (size_t)tid * EPT;
   int *tab = tables + (size_t)blockIdx.x * table_words(K);
 
-  // scheduler trailer behind the last table: the blur's tile-queue tickets start from zero
-  if (blockIdx.x == 0 && tid < SCHED_WORDS && (normalize & 8)) tables[(size_t)gridDim.x * table_words(K) + tid] = 0;
 
   // ---- one vectorised read of this thread's EPT consecutive elements ---------------------------
   T v[EPT];
@@ -415,7 +413,7 @@ extern "C" size_t dib_tap_table_bytes(int K) {
 
 extern "C" size_t dib_tap_tables_bytes(int K, int B) {
   if ((K != 128 && K != 256) || B < 0) return 0;
-  return ((size_t)dib::table_words(K) * B + dib::SCHED_WORDS) * sizeof(int);
+  return (size_t)dib::table_words(K) * B * sizeof(int);
 }
 
 static int launch_compact(const void *const *ptrs, int dtype, int B, int K, int normalize, int *tables, hipStream_t s) {
@@ -428,8 +426,7 @@ static int launch_compact(const void *const *ptrs, int dtype, int B, int K, int 
       pp.p[i] = ptrs[b0 + i];
     }
     int *t = tables + (size_t)b0 * stride;
-    // bit 3: this launch owns the scheduler trailer behind the LAST table (only the final chunk does)
-    const int flags = (normalize ? 1 : 0) | ((b0 + n == B) ? 8 : 0);
+    const int flags = normalize ? 1 : 0;
     if (dtype == DIB_F16 && K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 128>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
     else if (dtype == DIB_F16) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 256>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
     else if (K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<float, 128>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 1
+#define DIB_ABI_VERSION 2 /* 2: tap-table buffers carry no scheduler trailer any more */
 
 /* error codes */
 #define DIB_OK 0
@@ -60,15 +60,13 @@ const char *dib_last_error(void);
  * 16 bits) and the fp16 weight bits (high 16 bits).
  * ------------------------------------------------------------------------------------- */
 size_t dib_tap_table_bytes(int K); /* bytes of ONE table; K is 128 or 256 */
-/* bytes of the buffer dib_psf_compact fills for B PSFs: B tables followed by a 1 KiB trailer of
- * scheduler words (zeroed by dib_psf_compact, consumed by dib_sparse_blur's tile queue) */
+/* bytes of the buffer dib_psf_compact fills for B PSFs: B tables, dib_tap_table_bytes(K) apart */
 size_t dib_tap_tables_bytes(int K, int B);
 
 /* psf_dev: [B][K][K] of `dtype`.  normalize != 0 divides by the PSF's sum first, in the PSF's
  * dtype, exactly like `psf_GPU / psf_GPU.sum()` (blur_functions.py:98, utils.py:372); 0 takes the
  * weights as they are (manual_blur's contract, blur_functions.py:13).  tables_dev
- * (dib_tap_tables_bytes(K, B) bytes) receives B tables, dib_tap_table_bytes(K) apart, and the
- * zeroed scheduler trailer. */
+ * (dib_tap_tables_bytes(K, B) bytes) receives B tables, dib_tap_table_bytes(K) apart. */
 int dib_psf_compact(const void *psf_dev, int dtype, int B, int K, int normalize,
                     void *tables_dev, void *stream);
 /* same, for PSFs that live in B separate device buffers (host array of B device pointers, each
@@ -83,8 +81,8 @@ int dib_psf_compact_list(const void *const *psf_ptrs, int dtype, int B, int K, i
  * Host arrays of length B: in/out device pointers (C x H x W planar, `dtype`, contiguous;
  * out must not alias in), C, H, W and table_index (which table of tables_dev image i uses;
  * < 0 = leave the image untouched, i.e. blur_dict["blurring"] == False).  tables_dev is the buffer
- * dib_psf_compact filled for num_tables PSFs (its trailer holds the tile queue of this call: a
- * buffer serves one dib_sparse_blur call at a time, any number of calls one after another).  Padding mode follows
+ * dib_psf_compact filled for num_tables PSFs (read only: any number of dib_sparse_blur calls, on any
+ * streams, may share it).  Padding mode follows
  * the reference: K = 256 -> replicate; K = 128 -> zero if H < 64 or W < 64, else reflect.
  * Returns DIB_ESHAPE where the reference raises (K = 128 and H or W == 64).
  * ------------------------------------------------------------------------------------- */

@@ -29,7 +29,7 @@
 // fp32 (MI355X_MICROARCH.md: SIMD-32, v_fma_f32 2 cycles per wave).  The bit-exact contract needs a
 // multiply AND an add per 2 pixel-taps: 15.1 M wave-instructions for the BASELINE batch = ~26 us of
 // pure VALU time on 1024 SIMDs, above its 16 us HBM time.  Everything else -- window fills, stores,
-// launch ramp -- has to hide behind that arithmetic, i.e. behind the other three workgroups of the CU.
+// launch ramp -- has to hide behind that arithmetic: see "Persistent streaming kernel" below.
 #include "dib_common.h"
 #include <hip/hip_fp16.h>
 #include <mutex>
@@ -43,6 +43,8 @@ constexpr int PQ = WIN_PITCH;         // LDS row pitch in 8-byte words (96)
 constexpr int TH = 32;                // tile rows
 constexpr int LROWS = TH + SEG_ROWS;  // LDS rows per window (48)
 constexpr int LDS_BYTES = LROWS * PQ * 8;  // 36,864 B: four workgroups per CU
+constexpr int STREAM_LDS_BYTES = LDS_BYTES + 16;  // + the ticket mailbox of the persistent kernel
+constexpr int WG_PER_CU = 3;   // persistent kernel: 3 x 8 waves per CU = 6 per SIMD at <= 80 registers per lane
 static_assert(WIN_PITCH * 8 == 768, "the asm below hard-codes the LDS row pitch");
 
 // 64-bit asm operands must be scalar integers: hipcc (ROCm 7.2) aliases both lanes of a
@@ -125,10 +127,13 @@ typedef unsigned long long u2;
 #define DIB_NEXTTAP "s_load_dword %20, %22, %16\n\ts_add_u32 %16, %16, 4\n\t"
 
 // acc[i][0] / acc[i][1] (i = 0..7): the packed fp16 accumulators of this lane's 8 rows x 4 columns.
-// The loop opens with vmcnt(0): a window load whose value hipcc found no use for may still be in flight, and
-// hipcc is free to have put its destination into a register clobbered here; it waits before ITS OWN next write
-// to such a register, but not before this asm's.
-template <bool FUSED, bool HALF>
+// DRAIN: wait for every outstanding vector-memory operation before the loop (the one-tile-per-workgroup
+// kernel: window loads whose values were never used -- rows past the window's end -- may still be in
+// flight, and hipcc is free to have put their destinations into the registers clobbered here; it waits
+// before ITS OWN next write to such a register, but not before this asm's).  The streaming kernel keeps
+// the NEXT window's loads in flight across the loop; every one of them is consumed afterwards, so none
+// can sit in a clobbered register.
+template <bool FUSED, bool HALF, bool DRAIN>
 __device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
   // cnt = taps left minus one: the borrow of its decrement ends the loop (n >= 1 in every segment)
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
@@ -162,14 +167,26 @@ __device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long 
         "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "scc", \
         "memory")
 #define DIB_W_DRAIN "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+#define DIB_W_KEEP "s_waitcnt lgkmcnt(0)\n\t"
   if constexpr (HALF) {
-    if constexpr (FUSED) { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8H(64), DIB_READ8H(80), DIB_FMADDH_A, DIB_FMADDH_B); }
-    else { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8H(64), DIB_READ8H(80), DIB_MADDH_A, DIB_MADDH_B); }
+    if constexpr (FUSED) {
+      if constexpr (DRAIN) { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8H(64), DIB_READ8H(80), DIB_FMADDH_A, DIB_FMADDH_B); }
+      else { DIB_R8_ASM(DIB_W_KEEP, DIB_READ8H(64), DIB_READ8H(80), DIB_FMADDH_A, DIB_FMADDH_B); }
+    } else {
+      if constexpr (DRAIN) { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8H(64), DIB_READ8H(80), DIB_MADDH_A, DIB_MADDH_B); }
+      else { DIB_R8_ASM(DIB_W_KEEP, DIB_READ8H(64), DIB_READ8H(80), DIB_MADDH_A, DIB_MADDH_B); }
+    }
   } else {
-    if constexpr (FUSED) { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8(64), DIB_READ8(80), DIB_FMADD_A, DIB_FMADD_B); }
-    else { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8(64), DIB_READ8(80), DIB_MADD_A, DIB_MADD_B); }
+    if constexpr (FUSED) {
+      if constexpr (DRAIN) { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8(64), DIB_READ8(80), DIB_FMADD_A, DIB_FMADD_B); }
+      else { DIB_R8_ASM(DIB_W_KEEP, DIB_READ8(64), DIB_READ8(80), DIB_FMADD_A, DIB_FMADD_B); }
+    } else {
+      if constexpr (DRAIN) { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8(64), DIB_READ8(80), DIB_MADD_A, DIB_MADD_B); }
+      else { DIB_R8_ASM(DIB_W_KEEP, DIB_READ8(64), DIB_READ8(80), DIB_MADD_A, DIB_MADD_B); }
+    }
   }
 #undef DIB_W_DRAIN
+#undef DIB_W_KEEP
 #undef DIB_R8_ASM
 #pragma unroll
   for (int i = 0; i < 8; ++i) { acc[i][0] = __builtin_bit_cast(h2, a[2 * i]); acc[i][1] = __builtin_bit_cast(h2, a[2 * i + 1]); }
@@ -188,6 +205,70 @@ __device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long 
 #undef DIB_READ8
 #undef DIB_READ8H
 #undef DIB_NEXTTAP
+
+// ---- the same loop for 4 rows per lane (8-wave workgroups of the persistent kernel) -----------------------------------
+// buffers v[64:71] / v[72:79], LDS address v48.  Operands: %0-%7 accumulators, %8 byte offset of the next ltap,
+// %9 taps left, %10 A, %11 B, %12 C, %13 scalar temp, %14 ltaps, %15 lane base.
+#define DIB4_MUL(b) "v_pk_mul_f16 v" #b ", %10, v" #b " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+#define DIB4_ADD(b, i) "v_pk_add_f16 %" #i ", %" #i ", v" #b "\n\t"
+#define DIB4_FMA(b, i) "v_pk_fma_f16 %" #i ", %10, v" #b ", %" #i " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define DIB4_MADD_A DIB4_MUL(32) DIB4_MUL(33) DIB4_MUL(34) DIB4_MUL(35) DIB4_MUL(36) DIB4_MUL(37) DIB4_MUL(38) DIB4_MUL(39) \
+  DIB4_ADD(32, 0) DIB4_ADD(33, 1) DIB4_ADD(34, 2) DIB4_ADD(35, 3) DIB4_ADD(36, 4) DIB4_ADD(37, 5) DIB4_ADD(38, 6) DIB4_ADD(39, 7)
+#define DIB4_MADD_B DIB4_MUL(40) DIB4_MUL(41) DIB4_MUL(42) DIB4_MUL(43) DIB4_MUL(44) DIB4_MUL(45) DIB4_MUL(46) DIB4_MUL(47) \
+  DIB4_ADD(40, 0) DIB4_ADD(41, 1) DIB4_ADD(42, 2) DIB4_ADD(43, 3) DIB4_ADD(44, 4) DIB4_ADD(45, 5) DIB4_ADD(46, 6) DIB4_ADD(47, 7)
+#define DIB4_FMADD_A DIB4_FMA(32, 0) DIB4_FMA(33, 1) DIB4_FMA(34, 2) DIB4_FMA(35, 3) DIB4_FMA(36, 4) DIB4_FMA(37, 5) DIB4_FMA(38, 6) DIB4_FMA(39, 7)
+#define DIB4_FMADD_B DIB4_FMA(40, 0) DIB4_FMA(41, 1) DIB4_FMA(42, 2) DIB4_FMA(43, 3) DIB4_FMA(44, 4) DIB4_FMA(45, 5) DIB4_FMA(46, 6) DIB4_FMA(47, 7)
+#define DIB4_MADDH_A DIB4_MUL(32) DIB4_MUL(33) DIB4_MUL(34) DIB4_MUL(35) DIB4_ADD(32, 0) DIB4_ADD(33, 2) DIB4_ADD(34, 4) DIB4_ADD(35, 6)
+#define DIB4_MADDH_B DIB4_MUL(40) DIB4_MUL(41) DIB4_MUL(42) DIB4_MUL(43) DIB4_ADD(40, 0) DIB4_ADD(41, 2) DIB4_ADD(42, 4) DIB4_ADD(43, 6)
+#define DIB4_FMADDH_A DIB4_FMA(32, 0) DIB4_FMA(33, 2) DIB4_FMA(34, 4) DIB4_FMA(35, 6)
+#define DIB4_FMADDH_B DIB4_FMA(40, 0) DIB4_FMA(41, 2) DIB4_FMA(42, 4) DIB4_FMA(43, 6)
+#define DIB4_READ(base)                                                                                      \
+  "v_mad_u32_u16 v48, %11, 1, %15\n\t"                                                                       \
+  "ds_read_b64 v[" #base ":" #base "+1], v48\n\tds_read_b64 v[" #base "+2:" #base "+3], v48 offset:768\n\t"   \
+  "ds_read_b64 v[" #base "+4:" #base "+5], v48 offset:1536\n\tds_read_b64 v[" #base "+6:" #base "+7], v48 offset:2304\n\t"
+#define DIB4_READH(base)                                                                                     \
+  "v_mad_u32_u16 v48, %11, 1, %15\n\t"                                                                       \
+  "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+1], v48 offset:768\n\t"                           \
+  "ds_read_b32 v[" #base "+2], v48 offset:1536\n\tds_read_b32 v[" #base "+3], v48 offset:2304\n\t"
+#define DIB4_NEXTTAP "s_load_dword %12, %14, %8\n\ts_add_u32 %8, %8, 4\n\t"
+template <bool FUSED, bool HALF>
+__device__ __forceinline__ void tap_loop_r4(h2 (&acc)[4][2], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
+  unsigned sA, sB, sC, st;
+  unsigned a[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[2 * i] = __builtin_bit_cast(unsigned, acc[i][0]); a[2 * i + 1] = __builtin_bit_cast(unsigned, acc[i][1]); }
+#define DIB_R4_ASM(RD_A, RD_B, ARITH_A, ARITH_B) \
+  asm volatile( \
+      "s_load_dword %11, %14, %8\n\ts_add_u32 %8, %8, 4\n\t" DIB4_NEXTTAP \
+      "s_waitcnt lgkmcnt(0)\n\t" RD_A \
+      "Ldib4_loop%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
+      RD_B DIB4_NEXTTAP \
+      ARITH_A \
+      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 Ldib4_done%=\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
+      RD_A DIB4_NEXTTAP \
+      ARITH_B \
+      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc0 Ldib4_loop%=\n\t" \
+      "Ldib4_done%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)" \
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+s"(toff), "+s"(cnt), \
+        "=&s"(sA), "=&s"(sB), "=&s"(sC), "=&s"(st) \
+      : "s"(ltaps), "v"(lane_addr) \
+      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "scc", \
+        "memory")
+  if constexpr (HALF) {
+    if constexpr (FUSED) { DIB_R4_ASM(DIB4_READH(32), DIB4_READH(40), DIB4_FMADDH_A, DIB4_FMADDH_B); }
+    else { DIB_R4_ASM(DIB4_READH(32), DIB4_READH(40), DIB4_MADDH_A, DIB4_MADDH_B); }
+  } else {
+    if constexpr (FUSED) { DIB_R4_ASM(DIB4_READ(32), DIB4_READ(40), DIB4_FMADD_A, DIB4_FMADD_B); }
+    else { DIB_R4_ASM(DIB4_READ(32), DIB4_READ(40), DIB4_MADD_A, DIB4_MADD_B); }
+  }
+#undef DIB_R4_ASM
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i][0] = __builtin_bit_cast(h2, a[2 * i]); acc[i][1] = __builtin_bit_cast(h2, a[2 * i + 1]); }
+}
 
 // DIB_ACC_FP32: acc32 = acc32 + float(P) * float(w), taps in the same order, ONE rounding to fp16 at the
 // store.  The product of two fp16 values is exact in fp32 (11 + 11 <= 24 significand bits), so fused
@@ -233,9 +314,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *img_bas
   return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, H * W * 2, 0x00020000);
 }
 
-constexpr int NW = 4;                       // waves per workgroup
-constexpr int R = TH / NW;                  // rows per lane (8)
-constexpr int G = (LROWS + NW - 1) / NW;    // LDS rows a wave fills (12): all of them in ONE batch of loads
+// Scalar loads of table words, written out: inside the persistent kernel's loop hipcc will not use the scalar
+// cache for them (stores, atomics and asm statements in the loop count as possible clobbers of *tables), and its
+// vector-load fallback waits with vmcnt(0) -- on the ticket in flight and on every look-ahead load.
+__device__ __forceinline__ unsigned sload_u32(const void *p) {
+  unsigned r;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"((unsigned long long)p));
+  return r;
+}
+__device__ __forceinline__ uint4 sload_u128(const void *p) {
+  unsigned __int128 r;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"((unsigned long long)p));
+  return make_uint4((unsigned)r, (unsigned)(r >> 32), (unsigned)(r >> 64), (unsigned)(r >> 96));
+}
+
+constexpr int NW = 4;                       // one-tile-per-workgroup kernel: waves per workgroup
+constexpr int R = TH / NW;                  //   rows per lane (8)
+constexpr int G = (LROWS + NW - 1) / NW;    //   LDS rows a wave fills (12): all of them in ONE batch of loads
+constexpr int SNW = 8;                      // persistent kernel: waves per workgroup
+constexpr int SR = TH / SNW;                //   rows per lane (4)
+constexpr int SG = LROWS / SNW;             //   LDS rows a wave fills (6)
 
 // The window of one (tile, tap segment) as a wave sees it: what to load, and later what to write to LDS.
 struct Window {
@@ -343,27 +441,23 @@ __device__ __forceinline__ void write_window(unsigned wp, unsigned (&v)[G][5], u
 }
 
 // ---- store: lane owns columns x0 + lane + 64k ---------------------------------------------------------
-// No execution masks and no branches: the hardware drops a buffer store whose per-lane offset lies past the
-// descriptor's range.  Lanes whose column is outside the image get an out-of-range offset once per tile; a row
-// below the image (bottom tiles of an image whose height is not a multiple of 32) is stored through a descriptor of
-// range zero.  Always exactly 4 x R store instructions: the look-ahead of the strip loop relies on that count
-// (vector-memory operations retire in issue order; hipcc can only wait for "all but the last 32" if it is sure of the 32).
+// No execution masks: the plane's buffer descriptor covers exactly H * W * 2 bytes and the hardware drops a buffer
+// store whose per-lane offset lies past that range, so lanes whose column is outside the image get an out-of-range
+// offset once per tile.  (The scalar row offset takes no part in the range check: rows below the image are skipped.)
 template <int ACC, int R>
 __device__ __forceinline__ void store_tile(const h2 (&acc)[R][2], const float (&acc32)[R][4], void *out_base, int ch, int H, int W, int x0,
                                            int y0, int lane, int wave) {
-  const unsigned long long pa = (unsigned long long)out_base + (unsigned long long)ch * H * W * 2ull;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pa), hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
-  void *plane = (void *)(((unsigned long long)hi << 32) | lo);
+  const __amdgpu_buffer_rsrc_t out_rsrc = plane_rsrc(out_base, ch, H, W);
   const int w2 = W * 2;
   const int xr = W - x0 - lane;  // columns remaining for this lane
   const unsigned voff = 2u * (unsigned)(x0 + lane), oob = 0x7ffffff0u;
   const unsigned vo0 = xr > 0 ? voff : oob, vo1 = xr > 64 ? voff + 128u : oob, vo2 = xr > 128 ? voff + 256u : oob,
                  vo3 = xr > 192 ? voff + 384u : oob;
-  const int yb = y0 + wave * R;
+  const int s0 = (y0 + wave * R) * w2;
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(plane, 0, yb + i < H ? H * w2 : 0, 0x00020000);
-    const int soff = (yb + i) * w2;
+    if (y0 + wave * R + i >= H) break;   // wave-uniform
+    const int soff = s0 + i * w2;
     // halves are extracted with integer ops: hipcc (ROCm 7.2) stored the LOW half twice when the
     // high element of the fp16x2 accumulator was taken with a vector subscript
     unsigned a = __builtin_bit_cast(unsigned, acc[i][0]), b = __builtin_bit_cast(unsigned, acc[i][1]);
@@ -381,20 +475,9 @@ __device__ __forceinline__ void store_tile(const h2 (&acc)[R][2], const float (&
 }
 
 // =============================================================================================================
-// The tiled kernel: one workgroup = one (image, channel, 256 x 32 tile); fill -> taps -> store, the latencies of one
-// workgroup's phases hidden by the other three workgroups of its CU.
-// Round 2 built the alternative in full -- a PERSISTENT kernel (3 workgroups per CU for the whole launch) that issues
-// the window loads of tile n+1 before the tap loop of tile n (60 values in flight per lane), defers the stores of
-// tile n-1 behind the next barrier so they do not sit in front of those loads in the in-order vmcnt queue, runs a
-// static snake schedule over the per-XCD lists, and keeps only tile indices in SGPRs -- in a 4-wave x 8-row and an
-// 8-wave x 4-row form, both bit-identical to this kernel (scratch/blur_stream_experiment.hip, scratch/stamps_stream.py).
-// Measured on the BASELINE batch: 62.6 us (4 x 8, tap loops at raised priority) and 70.8 us (8 x 4) against 52 us
-// here.  Why: (1) the look-ahead costs 60 + 16 registers, i.e. one wave per SIMD (168 registers, 3 waves), and the
-// packed-fp16 issue rate of a SIMD grows with the number of waves that are inside tap loops at the same time
-// (scratch/ubench/ub_clk.hip: 5.1 / 4.4 / 3.0 / 2.6 cycles per instruction with 1 / 2 / 3 / 8 waves); (2) a dynamic
-// tile queue is not affordable: a returning device-scope atomic took ~10 us under the kernel's own load, twice a tap
-// loop (139 us per launch with tickets drawn one tile ahead); (3) with static shares the slowest workgroup ran 25 %
-// longer than the mean.  The hardware dispatcher of THIS kernel is the better tile queue.
+// One-tile-per-workgroup kernel: one workgroup = one (image, channel, 256 x 32 tile); fill -> taps -> store, the
+// latencies of one workgroup's phases hidden only by the other three workgroups of its CU.  Kept as the second
+// tiled implementation (DIB_ACC_FP32 runs on it; the parity tests compare it with the streaming kernel).
 // =============================================================================================================
 template <int ACC>
 __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx,
@@ -409,8 +492,7 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
   const unsigned long long la = (unsigned long long)(tab + table_ltaps_off(K));
   const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
                                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
-  const int x0 = tx * TILE_W;
-  const bool half = W - x0 <= 128;   // every valid column lies in the tile's first 128: the HALF tap loop
+  const int x0 = tx * TILE_W, y0 = ty * TH;
   const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(d.in, ch, H, W);
 
   h2 acc[R][2];
@@ -424,13 +506,12 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
   const unsigned lane_addr = lds0 + (unsigned)((wave * R) * PQ + lane) * 8u;
   const int qb = wave * G;
   const unsigned wp = lds0 + (unsigned)(qb * PQ + lane) * 8u;
-  unsigned v[G][5];
-  unsigned zmask;
 
   stamp(dbg, 0);
-  const int y0 = ty * TH;
   for (int sg = 0; sg < nsegs; ++sg) {
     const Window w = window_of(segs[sg]);
+    unsigned v[G][5];
+    unsigned zmask;
     issue_window_loads(v, zmask, in_rsrc, w, x0, y0, H, W, K, mode, lane, qb);
     if (sg > 0) __syncthreads();  // every wave is done reading the previous segment's window
     write_window(wp, v, zmask, lane < w.cmax - w.cmin);
@@ -439,8 +520,7 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
     // the table pointer itself (kernel-argument derived, provably uniform): hipcc then fetches the ltap words
     // with scalar loads; a pointer rebuilt from an integer would go through per-lane flat loads
     if constexpr (ACC == DIB_ACC_FP32) tap_loop_fp32<R>(acc32, reinterpret_cast<const unsigned *>(tab + table_ltaps_off(K)), w.t0, w.n, lane_addr);
-    else if (half) tap_loop_r8<ACC == DIB_ACC_FMA16, true>(acc, ltaps, w.t0, w.n, lane_addr);
-    else tap_loop_r8<ACC == DIB_ACC_FMA16, false>(acc, ltaps, w.t0, w.n, lane_addr);
+    else tap_loop_r8<ACC == DIB_ACC_FMA16, false, true>(acc, ltaps, w.t0, w.n, lane_addr);
     if (sg == 0) stamp(dbg, 2);
   }
   store_tile<ACC, R>(acc, acc32, d.out, ch, H, W, x0, y0, lane, wave);
@@ -464,187 +544,7 @@ __device__ __forceinline__ bool list_lookup(const BlurBatch &batch, int x, int t
   return false;
 }
 
-// =============================================================================================================
-// Narrow shape: 128 x 32 tiles.  Lane l owns columns x0 + l and x0 + l + 64 (ONE packed register per row), the LDS
-// word is 4 bytes {P[j], P[j+64]} and the window 48 rows x 96 words x 4 B = 18 KB: seven workgroups per CU instead of
-// four.  The kernel is a closed system -- a CU's slots each run dispatch -> prologue -> fill -> taps -> store in
-// sequence, and its time is (tiles per slot) x (latency of one workgroup) -- so slots are what buys throughput:
-// measured on the BASELINE batch 3 / 4 slots gave 61 / 51 us with the 256-wide tile.  Costs: 1.25 x instead of
-// 1.125 x halo columns, and twice the workgroups (their fixed cost is ~2.4 us each).
-// =============================================================================================================
-constexpr int NTILE_W = 128;
-constexpr int NPITCH = WIN_PITCH * 4;         // bytes per LDS row (384)
-constexpr int NLDS_BYTES = LROWS * NPITCH;    // 18,432 B
-static_assert(NPITCH == 384, "the asm below hard-codes the LDS row pitch");
-
-// The r8 tap loop on 4-byte words: the ltap word carries the byte offset of the 8-byte-word layout, so it is halved
-// (s_bfe_u32: bits 15..1) -- one more scalar instruction per tap.  Buffers v[32:39] / v[40:47], address v48.
-// Operands: %0-%7 accumulators, %8 byte offset of the next ltap, %9 taps left, %10 A, %11 B, %12 C, %13 temp, %14 ltaps, %15 lane base.
-#define DIBN_MUL(b) "v_pk_mul_f16 v" #b ", %10, v" #b " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
-#define DIBN_ADD(b, i) "v_pk_add_f16 %" #i ", %" #i ", v" #b "\n\t"
-#define DIBN_FMA(b, i) "v_pk_fma_f16 %" #i ", %10, v" #b ", %" #i " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-#define DIBN_MADD_A DIBN_MUL(32) DIBN_MUL(33) DIBN_MUL(34) DIBN_MUL(35) DIBN_MUL(36) DIBN_MUL(37) DIBN_MUL(38) DIBN_MUL(39) \
-  DIBN_ADD(32, 0) DIBN_ADD(33, 1) DIBN_ADD(34, 2) DIBN_ADD(35, 3) DIBN_ADD(36, 4) DIBN_ADD(37, 5) DIBN_ADD(38, 6) DIBN_ADD(39, 7)
-#define DIBN_MADD_B DIBN_MUL(40) DIBN_MUL(41) DIBN_MUL(42) DIBN_MUL(43) DIBN_MUL(44) DIBN_MUL(45) DIBN_MUL(46) DIBN_MUL(47) \
-  DIBN_ADD(40, 0) DIBN_ADD(41, 1) DIBN_ADD(42, 2) DIBN_ADD(43, 3) DIBN_ADD(44, 4) DIBN_ADD(45, 5) DIBN_ADD(46, 6) DIBN_ADD(47, 7)
-#define DIBN_FMADD_A DIBN_FMA(32, 0) DIBN_FMA(33, 1) DIBN_FMA(34, 2) DIBN_FMA(35, 3) DIBN_FMA(36, 4) DIBN_FMA(37, 5) DIBN_FMA(38, 6) DIBN_FMA(39, 7)
-#define DIBN_FMADD_B DIBN_FMA(40, 0) DIBN_FMA(41, 1) DIBN_FMA(42, 2) DIBN_FMA(43, 3) DIBN_FMA(44, 4) DIBN_FMA(45, 5) DIBN_FMA(46, 6) DIBN_FMA(47, 7)
-#define DIBN_READ(base)                                                                                      \
-  "s_bfe_u32 %13, %11, 0xf0001\n\tv_add_u32 v48, %13, %15\n\t"                                                \
-  "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+1], v48 offset:384\n\t"                           \
-  "ds_read_b32 v[" #base "+2], v48 offset:768\n\tds_read_b32 v[" #base "+3], v48 offset:1152\n\t"             \
-  "ds_read_b32 v[" #base "+4], v48 offset:1536\n\tds_read_b32 v[" #base "+5], v48 offset:1920\n\t"            \
-  "ds_read_b32 v[" #base "+6], v48 offset:2304\n\tds_read_b32 v[" #base "+7], v48 offset:2688\n\t"
-#define DIBN_NEXTTAP "s_load_dword %12, %14, %8\n\ts_add_u32 %8, %8, 4\n\t"
-template <bool FUSED>
-__device__ __forceinline__ void tap_loop_narrow(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
-  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
-  unsigned sA, sB, sC, st;
-  unsigned a[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
-#define DIB_RN_ASM(ARITH_A, ARITH_B) \
-  asm volatile( \
-      "s_load_dword %11, %14, %8\n\ts_add_u32 %8, %8, 4\n\t" DIBN_NEXTTAP \
-      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIBN_READ(32) \
-      "Ldibn_loop%=:\n\t" \
-      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
-      DIBN_READ(40) DIBN_NEXTTAP \
-      ARITH_A \
-      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 Ldibn_done%=\n\t" \
-      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
-      DIBN_READ(32) DIBN_NEXTTAP \
-      ARITH_B \
-      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc0 Ldibn_loop%=\n\t" \
-      "Ldibn_done%=:\n\t" \
-      "s_waitcnt lgkmcnt(0)" \
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+s"(toff), "+s"(cnt), \
-        "=&s"(sA), "=&s"(sB), "=&s"(sC), "=&s"(st) \
-      : "s"(ltaps), "v"(lane_addr) \
-      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "scc", \
-        "memory")
-  if constexpr (FUSED) { DIB_RN_ASM(DIBN_FMADD_A, DIBN_FMADD_B); } else { DIB_RN_ASM(DIBN_MADD_A, DIBN_MADD_B); }
-#undef DIB_RN_ASM
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
-}
-
-template <int ACC>
-__device__ __forceinline__ void blur_narrow_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
-                                                     unsigned *lds) {
-#pragma clang fp contract(off)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = d.H, W = d.W, w2 = W * 2;
-  const int mode = pad_mode_for(K, H, W);
-  const int pb = K / 2 - 1, pa = K / 2;
-  const int nsegs = tab[HDR_NSEGS];
-  const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
-  const unsigned long long la = (unsigned long long)(tab + table_ltaps_off(K));
-  const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
-                                   (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
-  const int x0 = tx * NTILE_W, y0 = ty * TH;
-  const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(d.in, ch, H, W);
-  h2 acc[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) acc[i] = h2{0, 0};
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
-  const unsigned lane_addr = lds0 + (unsigned)((wave * R) * NPITCH + lane * 4);
-  const int qb = wave * G;
-  const unsigned wp = lds0 + (unsigned)(qb * NPITCH + lane * 4);
-  typedef __attribute__((address_space(3))) unsigned lds_u1;
-
-  for (int sg = 0; sg < nsegs; ++sg) {
-    const Window w = window_of(segs[sg]);
-    // ---- fill: per LDS row the three values P[lane + 64k] ---------------------------------------------------------
-    unsigned v[G][3], coff[3];
-    int soff[G];
-    unsigned zmask = 0;
-    const int c_first = x0 + pb - w.cmax, r_first = y0 + pb - w.rl;
-    const bool zero_mode = mode == PAD_ZERO;
-    if (!zero_mode && c_first >= 0 && c_first + 63 + 128 <= W - 1) {
-      const unsigned c0 = 2u * (unsigned)(c_first + lane);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) coff[k] = c0 + 128u * k;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        bool z;
-        coff[k] = 2u * (unsigned)map_coord_sel(c_first + lane + 64 * k, W, pa, pb, mode, z);
-        zmask |= z ? 1u << k : 0u;
-      }
-    }
-    if (!zero_mode && r_first >= 0 && r_first + LROWS - 1 <= H - 1) {
-      const int s0 = (r_first + qb) * w2;
-#pragma unroll
-      for (int g = 0; g < G; ++g) soff[g] = s0 + g * w2;
-    } else {
-      const int nrows = TH + (w.rl - w.rf);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        bool zr;
-        const int sr = map_coord_sel(r_first + min(qb + g, nrows - 1), H, pa, pb, mode, zr);
-        zmask |= zr ? 1u << (8 + g) : 0u;
-        soff[g] = sr * w2;
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int so = __builtin_amdgcn_readfirstlane(soff[g]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) v[g][k] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
-    }
-    if (sg > 0) __syncthreads();  // every wave is done reading the previous window
-    const bool second = lane < w.cmax - w.cmin;
-    const bool masked = __builtin_amdgcn_ballot_w64(zmask != 0) != 0;   // PAD_ZERO images only
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (masked) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u)) v[g][k] = 0;
-      }
-      const unsigned w0 = v[g][0] | (v[g][1] << 16);
-      *(lds_u1 *)(size_t)(wp + (unsigned)(g * NPITCH)) = w0;
-      if (second) *(lds_u1 *)(size_t)(wp + (unsigned)(g * NPITCH + 256)) = __builtin_amdgcn_alignbit(v[g][2], w0, 16);
-    }
-    __syncthreads();
-    tap_loop_narrow<ACC == DIB_ACC_FMA16>(acc, ltaps, w.t0, w.n, lane_addr);
-  }
-  // ---- store (see store_tile: out-of-range lanes get an out-of-range offset, rows below the image a null descriptor) ----
-  {
-    const unsigned long long pa2 = (unsigned long long)d.out + (unsigned long long)ch * H * W * 2ull;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pa2), hi = __builtin_amdgcn_readfirstlane((unsigned)(pa2 >> 32));
-    void *plane = (void *)(((unsigned long long)hi << 32) | lo);
-    const int xr = W - x0 - lane;
-    const unsigned voff = 2u * (unsigned)(x0 + lane), oob = 0x7ffffff0u;
-    const unsigned vo0 = xr > 0 ? voff : oob, vo1 = xr > 64 ? voff + 128u : oob;
-    const int yb = y0 + wave * R;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(plane, 0, yb + i < H ? H * w2 : 0, 0x00020000);
-      const int so = (yb + i) * w2;
-      const unsigned a = __builtin_bit_cast(unsigned, acc[i]);
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a & 0xffffu), out_rsrc, vo0, so, 0);
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a >> 16), out_rsrc, vo1, so, 0);
-    }
-  }
-}
-
-template <int ACC>
-__global__ __launch_bounds__(256, 7) void blur_narrow_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K) {
-  extern __shared__ unsigned nlds[];
-  int i, local;
-  if (!list_lookup(batch, blockIdx.x & 7, blockIdx.x >> 3, i, local)) return;  // the grid is 8 x the longest list
-  const ImageDesc &d = batch.img[i];
-  const int per_ch = d.tiles_x * d.tiles_y;
-  const int ch = local / per_ch;
-  local -= ch * per_ch;
-  const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
-  blur_narrow_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, nlds);
-}
-
-template <int ACC>
+template <int ACC = DIB_ACC_BITEXACT>
 __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K,
                                                                      unsigned long long *dbg) {
   extern __shared__ uint2 lds[];
@@ -665,6 +565,180 @@ __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch b
   local -= ch * per_ch;
   const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
   blur_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, lds, dbg);
+}
+
+// =============================================================================================================
+// Persistent streaming kernel (the default for fp16 images): 3 workgroups per CU live for the whole launch and
+// walk their share of the eight per-XCD tile lists (see "Tile order").  What it buys over one tile per workgroup:
+//   * the window loads of tile n+1 are ISSUED before the tap loop of tile n and land while it runs (60 values in
+//     flight per lane, registers only: LDS keeps one window).  A wave then spends its life inside tap loops; fills
+//     cost their issue slots, not their latency -- from HBM as from L2;
+//   * 768 workgroup launches instead of 3600 (the dispatcher starts ~1 wave/ns: 14,400 waves were 16 us of
+//     dispatch) and no per-tile relaunch gap;
+//   * stores are deferred by one tile and go out in FRONT of the look-ahead loads (see below);
+//   * tiles whose valid columns fit in 128 (the right-hand edge of 1333 = 5 x 256 + 53) run the HALF tap loop.
+// Schedule: STATIC.  Workgroup b serves list b % 8 (workgroups with equal b % 8 share an XCD and its L2 under the
+// round-robin placement the hardware uses; a speed matter only -- every entry of every list is served exactly once
+// whatever the placement) and takes entries b / 8, b / 8 + S, b / 8 + 2 S, ... with S = gridDim / 8.  Lists are in
+// descriptor order, heaviest image first (blur_functions hands them over that way), so every workgroup gets a
+// heavy-to-light spread and the odd extra tile is a light one.  (Built and measured first: dynamic tickets from
+// per-XCD atomic heads, drawn two tiles ahead.  A returning device-scope atomic on this path takes ~10 us under the
+// kernel's own load -- twice a tap loop -- so every tile waited for its ticket: 139 us per launch against 96 us for
+// the same code with static tickets.)
+// Per-tile bookkeeping is kept off the scalar unit (ONE per CU, shared by its twelve waves and by the 7 scalar
+// instructions of every tap): the image a tile belongs to changes ~8 times in a workgroup's life, so its descriptor,
+// table header and first segment sit in SGPRs (ImageCtx) and are re-read only then; tile -> (channel, row, column)
+// uses host-computed reciprocals instead of integer division.
+// =============================================================================================================
+// entry of an image's tile index -> channel and origin (reciprocals from the host: no integer division)
+__device__ __forceinline__ void tile_geom(const ImageDesc &d, int local, int &ch, int &x0, int &y0) {
+  const int per_ch = d.tiles_x * d.tiles_y;
+  // inv == 0 stands for a divisor of 1 (its reciprocal 2^32 does not fit)
+  ch = d.inv_per_ch ? (int)__umulhi((unsigned)local, d.inv_per_ch) : local;
+  local -= ch * per_ch;
+  const int ty = d.inv_tiles_x ? (int)__umulhi((unsigned)local, d.inv_tiles_x) : local, tx = local - ty * d.tiles_x;
+  x0 = tx * TILE_W; y0 = ty * TH;
+}
+
+template <int ACC>
+__global__ __launch_bounds__(64 * SNW, WG_PER_CU * SNW / 4) void blur_stream_f16_kernel(BlurBatch batch, QueueInfo qi, const int *__restrict__ tables, int K,
+                                                                             unsigned long long *dbg, int prio) {
+#pragma clang fp contract(off)
+  extern __shared__ uint2 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+  const unsigned lane_addr = lds0 + (unsigned)((wave * SR) * PQ + lane) * 8u;
+  const int qb = wave * SG;
+  const unsigned wp = lds0 + (unsigned)(qb * PQ + lane) * 8u;
+
+  const int list = (int)(blockIdx.x & 7u);
+  const int stride = (int)(gridDim.x >> 3);          // the host launches a multiple of 8 workgroups
+  const int len = qi.len[list];
+  const int j = (int)(blockIdx.x >> 3);             // this workgroup's column in the schedule
+  // Round r of the schedule hands entries [r * stride, (r + 1) * stride) to the workgroups of the list, in
+  // alternating direction ("snake"): entries are sorted heavy to light, so a workgroup that got the heaviest entry of
+  // one round gets the lightest of the next, and the sums even out.
+  int round = 0;
+  auto entry_of = [&](int r) { return r * stride + ((r & 1) ? stride - 1 - j : j); };
+  int entry = entry_of(0);                          // list entry of the tile whose window is (about to be) in flight
+  if (entry >= len) return;
+
+  // Only INDICES travel from tile to tile (image, tile inside the image): whatever a phase needs of an image it
+  // re-reads from the kernel arguments through the scalar cache.  A context kept in registers instead (pointers,
+  // shapes, table header, first segment: ~50 SGPRs for the three tiles in flight) spilled into VGPR lanes and paid a
+  // v_readlane in front of most instructions of the fill, store and issue phases.
+  int lk = 0, l_lo = 0, l_hi = 0, l_first = 0;      // look-ahead cursor: image lk holds list entries [l_lo, l_hi)
+  auto advance_to = [&](int e) {                    // entries only grow, so images only advance
+    for (;;) {
+      const int T = batch.tile_begin[lk + 1] - batch.tile_begin[lk];
+      l_first = (list * T) >> 3;
+      l_hi = l_lo + ((((list + 1) * T) >> 3) - l_first);
+      if (e < l_hi) break;
+      l_lo = l_hi; ++lk;
+    }
+  };
+
+  unsigned v[SG][5];
+  unsigned zmask = 0;
+  h2 acc[SR][2], out[SR][2];
+#pragma unroll
+  for (int i = 0; i < SR; ++i) { acc[i][0] = h2{0, 0}; acc[i][1] = h2{0, 0}; out[i][0] = h2{0, 0}; out[i][1] = h2{0, 0}; }
+  const float none32[SR][4] = {};
+  Window win;                                       // the window whose loads are in flight in v[][]
+
+  // loads of (image k, tile local, segment sg) -> v[][]; leaves the segment's description in `win`
+  auto issue = [&](int k, int local, int sg) {
+    const ImageDesc &d = batch.img[k];
+    int ch, x0, y0;
+    tile_geom(d, local, ch, x0, y0);
+    const int *tab = tables + (size_t)d.table * table_words(K);
+    win = window_of(sload_u128(reinterpret_cast<const uint4 *>(tab + table_segs_off(K)) + sg));
+    issue_window_loads(v, zmask, plane_rsrc(d.in, ch, d.H, d.W), win, x0, y0, d.H, d.W, K, pad_mode_for(K, d.H, d.W), lane, qb);
+  };
+
+  // ---- prologue: first tile, its first window in flight ------------------------------------------------------------
+  advance_to(entry);
+  int ck = lk, clocal = l_first + (entry - l_lo);   // tile being computed
+  int pk = 0, plocal = 0;                           // tile waiting to be stored
+  bool have_prev = false;
+  issue(ck, clocal, 0);
+
+  // diagnostics (dbg == nullptr in every product launch): shader cycles this workgroup's wave 0 spent per phase
+  unsigned long long ph_fill = 0, ph_store = 0, ph_issue = 0, ph_taps = 0, t_mark = 0, ntiles = 0;
+  const unsigned long long t_begin = dbg ? __builtin_readcyclecounter() : 0;
+  auto lap = [&](unsigned long long &bucket) {
+    if (dbg) { const unsigned long long now = __builtin_readcyclecounter(); bucket += now - t_mark; t_mark = now; }
+  };
+  t_mark = t_begin;
+
+  // Stores are DEFERRED by one tile: the results of tile n-1 wait in out[][] and are stored behind barrier B of tile n,
+  // in FRONT of the look-ahead loads.  Vector-memory operations retire in issue order (one vmcnt for loads and stores):
+  // stores issued behind the look-ahead loads would have to complete (write acknowledgement) before the next window
+  // can be written; issued in front of them they have a whole tap loop to drain.
+  while (true) {
+    const ImageDesc &cd = batch.img[ck];
+    const int *c_tab = tables + (size_t)cd.table * table_words(K);
+    const int c_nsegs = (int)sload_u32(c_tab + HDR_NSEGS);
+    const unsigned long long la = (unsigned long long)(c_tab + table_ltaps_off(K));
+    const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
+    int c_ch, c_x0, c_y0;
+    tile_geom(cd, clocal, c_ch, c_x0, c_y0);
+    const bool half = cd.W - c_x0 <= 128;           // every valid column of the tile lies in its first 128
+    const int next_entry = entry_of(round + 1);
+    const bool more = next_entry < len;
+    int nk = ck, nlocal = clocal;
+    for (int sg = 0; sg < c_nsegs; ++sg) {
+      const Window w = win;                       // in flight in v[][]
+      __syncthreads();                            // A: every wave is done reading the previous window
+      write_window(wp, v, zmask, lane < w.cmax - w.cmin);
+      __syncthreads();                            // B: window complete
+      lap(ph_fill);
+      if (sg == 0 && have_prev) {
+        const ImageDesc &pd = batch.img[pk];
+        int p_ch, p_x0, p_y0;
+        tile_geom(pd, plocal, p_ch, p_x0, p_y0);
+        store_tile<DIB_ACC_BITEXACT, SR>(out, none32, pd.out, p_ch, pd.H, pd.W, p_x0, p_y0, lane, wave);
+      }
+      lap(ph_store);
+      // ---- look-ahead: the next window's loads go out before this one's tap loop ----------------------------------
+      if (sg + 1 < c_nsegs) {                     // next segment of this tile (PSFs wider / taller than one window)
+        issue(ck, clocal, sg + 1);
+      } else if (more) {
+        advance_to(next_entry);
+        nk = lk; nlocal = l_first + (next_entry - l_lo);
+        issue(nk, nlocal, 0);
+      }
+      lap(ph_issue);
+      if (prio == 1) __builtin_amdgcn_s_setprio(0); else if (prio == 2) __builtin_amdgcn_s_setprio(3);
+      // ---- taps of this segment -------------------------------------------------------------------------------------
+      if (half) tap_loop_r4<ACC == DIB_ACC_FMA16, true>(acc, ltaps, w.t0, w.n, lane_addr);
+      else tap_loop_r4<ACC == DIB_ACC_FMA16, false>(acc, ltaps, w.t0, w.n, lane_addr);
+      if (prio == 1) __builtin_amdgcn_s_setprio(3); else if (prio == 2) __builtin_amdgcn_s_setprio(0);
+      lap(ph_taps);
+    }
+#pragma unroll
+    for (int i = 0; i < SR; ++i) {
+      out[i][0] = acc[i][0]; out[i][1] = acc[i][1];
+      acc[i][0] = h2{0, 0}; acc[i][1] = h2{0, 0};
+    }
+    pk = ck; plocal = clocal; have_prev = true;
+    ++ntiles;
+    if (!more) break;
+    entry = next_entry; ++round; ck = nk; clocal = nlocal;
+  }
+  {
+    const ImageDesc &pd = batch.img[pk];
+    int p_ch, p_x0, p_y0;
+    tile_geom(pd, plocal, p_ch, p_x0, p_y0);
+    store_tile<DIB_ACC_BITEXACT, SR>(out, none32, pd.out, p_ch, pd.H, pd.W, p_x0, p_y0, lane, wave);
+  }
+  if (dbg && tid == 0) {
+    unsigned long long *o = dbg + (size_t)blockIdx.x * 8;
+    o[0] = ph_fill; o[1] = ph_store; o[2] = ph_issue; o[3] = ph_taps; o[4] = 0;
+    o[5] = __builtin_readcyclecounter() - t_begin; o[6] = ntiles; o[7] = (unsigned long long)list;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -723,22 +797,20 @@ __global__ __launch_bounds__(256) void blur_generic_kernel(BlurBatch batch, cons
 
 using namespace dib;
 
-// Diagnostics only: when set, the tiled kernel records per-workgroup phase stamps (8 x u64 each).
+// Diagnostics only: when set, the one-tile-per-workgroup kernel records per-workgroup phase stamps (8 x u64 each).
 static unsigned long long *g_stamp_buffer = nullptr;
 extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) { g_stamp_buffer = (unsigned long long *)dev_ptr; }
-// Tile order of the tiled kernel: 1 = per-XCD bands (default), 0 = flat (the traffic experiment of DESIGN.md section 4).
-static int g_xcd_bands = 1;
-// Tile shape serving fp16 images in the bit-exact and FMA16 modes (both shapes bit-identical; tests/test_blur_gpu.py
-// compares them): 0 = 128 x 32 "narrow" tiles, 8 workgroups per CU (default), 1 = 256 x 32 tiles, 4 per CU (also what
-// DIB_ACC_FP32 runs on).
-static int g_shape = 0;
-extern "C" void dib_debug_set_shape(int shape) { g_shape = shape == 1 ? 1 : 0; }
+// Which tiled implementation serves fp16 images (both bit-identical; tests/test_blur_gpu.py compares them):
+// 0 = persistent streaming kernel (default), 1 = one tile per workgroup.  `xcd_bands` = 0 gives the latter a flat
+// tile order (the traffic experiment of DESIGN.md section 4).
+static int g_variant = 0, g_xcd_bands = 1, g_prio = 0;
 extern "C" void dib_debug_set_tile_order(int xcd_bands) { g_xcd_bands = xcd_bands ? 1 : 0; }
+extern "C" void dib_debug_set_variant(int variant, int prio) { g_variant = variant == 1 ? 1 : 0; g_prio = prio; }
 
 namespace {
-// Per-device launch state: the dynamic-LDS opt-in is a per-device function attribute.  Guarded by a mutex: entry
-// points may be called from several host threads.
-struct DeviceState { bool ready = false; };
+// Per-device launch state: the dynamic-LDS opt-in is a per-device function attribute, and the persistent grid is
+// sized from the device's CU count.  Guarded by a mutex: entry points may be called from several host threads.
+struct DeviceState { bool ready = false; int cus = 0; };
 std::mutex g_dev_mutex;
 DeviceState g_dev[64];
 
@@ -746,7 +818,7 @@ template <typename Kern> hipError_t opt_in(Kern k, int bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int prepare_device() {
+int prepare_device(int *cus) {
   int dev = 0;
   DIB_HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) { set_error("dib_sparse_blur: device index %d out of range", dev); return DIB_EINVAL; }
@@ -756,10 +828,12 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_BITEXACT>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FP32>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FMA16>, LDS_BYTES));
-    DIB_HIP_CHECK(opt_in(blur_narrow_f16_kernel<DIB_ACC_BITEXACT>, NLDS_BYTES));
-    DIB_HIP_CHECK(opt_in(blur_narrow_f16_kernel<DIB_ACC_FMA16>, NLDS_BYTES));
+    DIB_HIP_CHECK(opt_in(blur_stream_f16_kernel<DIB_ACC_BITEXACT>, STREAM_LDS_BYTES));
+    DIB_HIP_CHECK(opt_in(blur_stream_f16_kernel<DIB_ACC_FMA16>, STREAM_LDS_BYTES));
+    DIB_HIP_CHECK(hipDeviceGetAttribute(&st.cus, hipDeviceAttributeMultiprocessorCount, dev));
     st.ready = true;
   }
+  *cus = st.cus;
   return DIB_OK;
 }
 }  // namespace
@@ -792,19 +866,24 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   for (int i = 0; i < B; ++i)
     if (table_index[i] >= num_tables) { set_error("dib_sparse_blur: table_index[%d] = %d out of range", i, table_index[i]); return DIB_EINVAL; }
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = prepare_device()) return rc;
+  int cus = 0;
+  if (int rc = prepare_device(&cus)) return rc;
   int i = 0;
   while (i < B) {
     BlurBatch tiled, generic;
-    const bool narrow = g_shape == 0 && dtype == DIB_F16 && acc_mode != DIB_ACC_FP32;
     tiled.n = generic.n = 0;
     int tiles = 0, gblocks = 0;
+    bool small_images = true;   // the persistent kernel's reciprocal tile arithmetic holds
     for (; i < B && tiled.n < MAX_BATCH; ++i) {
       if (table_index[i] < 0) continue;
       ImageDesc d;
       d.in = in_dev[i]; d.out = out_dev[i]; d.C = C[i]; d.H = H[i]; d.W = W[i]; d.table = table_index[i];
-      d.tiles_x = narrow ? (W[i] + NTILE_W - 1) / NTILE_W : (W[i] + TILE_W - 1) / TILE_W;
+      d.tiles_x = (W[i] + TILE_W - 1) / TILE_W;
       d.tiles_y = (H[i] + TH - 1) / TH;
+      // ceil(2^32 / d): umulhi(n, inv) == n / d for n * d < 2^32, i.e. for every tile index of an image with < 65,536 tiles
+      d.inv_tiles_x = (unsigned)((0x100000000ull + (unsigned)d.tiles_x - 1) / (unsigned)d.tiles_x);
+      d.inv_per_ch = (unsigned)((0x100000000ull + (unsigned)(d.tiles_x * d.tiles_y) - 1) / (unsigned)(d.tiles_x * d.tiles_y));
+      small_images = small_images && (long long)d.C * d.tiles_x * d.tiles_y < 65536;
       d.tile_begin = tiles;
       tiled.tile_begin[tiled.n] = tiles;
       tiles += d.C * d.tiles_x * d.tiles_y;
@@ -821,24 +900,34 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     generic.xcd_bands = 0;
     if (dtype == DIB_F16) {
       for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
-      int grid = tiles;
-      if (g_xcd_bands) {   // 8 x the longest per-XCD list (lists differ by at most one tile per image)
-        int longest = 0;
-        for (int x = 0; x < 8; ++x) {
-          int len = 0;
-          for (int k = 0; k < tiled.n; ++k) {
-            const int T = tiled.tile_begin[k + 1] - tiled.tile_begin[k];
-            len += (((x + 1) * T) >> 3) - ((x * T) >> 3);
-          }
-          longest = len > longest ? len : longest;
+      // the eight per-XCD lists (lists differ by at most one tile per image)
+      QueueInfo qi;
+      int longest = 0;
+      for (int x = 0; x < 8; ++x) {
+        int len = 0;
+        for (int k = 0; k < tiled.n; ++k) {
+          const int T = tiled.tile_begin[k + 1] - tiled.tile_begin[k];
+          len += (((x + 1) * T) >> 3) - ((x * T) >> 3);
         }
-        grid = 8 * longest;
+        qi.len[x] = len;
+        longest = len > longest ? len : longest;
       }
-      if (narrow && acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_FMA16>), dim3(grid), dim3(256), NLDS_BYTES, s, tiled, (const int *)tables_dev, K);
-      else if (narrow) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_BITEXACT>), dim3(grid), dim3(256), NLDS_BYTES, s, tiled, (const int *)tables_dev, K);
-      else if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FP32>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
-      else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FMA16>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
-      else hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_BITEXACT>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      const bool streaming = g_variant == 0 && acc_mode != DIB_ACC_FP32 && small_images;
+      if (streaming) {
+        // persistent: every workgroup resident at once, one share of workgroups per list.  The share is the smallest
+        // one that needs no more rounds than the largest possible share would: every workgroup then serves the same
+        // number of tiles (+- 1) instead of a few of them serving one more.
+        const int share_max = WG_PER_CU * cus / 8 > 0 ? WG_PER_CU * cus / 8 : 1;
+        const int rounds = (longest + share_max - 1) / share_max;
+        const int grid = 8 * ((longest + rounds - 1) / rounds);
+        if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_stream_f16_kernel<DIB_ACC_FMA16>), dim3(grid), dim3(64 * SNW), STREAM_LDS_BYTES, s, tiled, qi, (const int *)tables_dev, K, g_stamp_buffer, g_prio);
+        else hipLaunchKernelGGL((blur_stream_f16_kernel<DIB_ACC_BITEXACT>), dim3(grid), dim3(64 * SNW), STREAM_LDS_BYTES, s, tiled, qi, (const int *)tables_dev, K, g_stamp_buffer, g_prio);
+      } else {
+        const int grid = g_xcd_bands ? 8 * longest : tiles;
+        if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FP32>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+        else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FMA16>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+        else hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_BITEXACT>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      }
     } else {
       hipLaunchKernelGGL((blur_generic_kernel<float, DIB_ACC_BITEXACT>), dim3(gblocks), dim3(256), 0, s, generic, (const int *)tables_dev, K);
     }

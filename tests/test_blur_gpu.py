@@ -376,17 +376,22 @@ def test_repeated_full_size_batches_are_deterministic(golden):
                 assert torch.equal(a, b)
 
 
-def test_kernel_variants_are_bit_identical():
-    """The 4-wave / 8-wave workgroup variants (two hand-written tap loops) and the 1- / 2-tile-per-
-    workgroup variants must agree bit for bit with the oracle on a ragged batch of all PSF classes."""
+def test_tile_shapes_and_orders_are_bit_identical():
+    """The two tile shapes (128 x 32 "narrow", the default, and 256 x 32 with its HALF tap loop on edge tiles of <= 128
+    valid columns), per-XCD banded and flat tile order, interior and border windows, zero-padded small images: all
+    bit-identical to the oracle on a ragged batch of all PSF classes."""
     import ctypes
     from detectinblur_amd import _lib, blur_ops
     l = _lib.lib()
-    l.dib_debug_set_variant.argtypes = [ctypes.c_int, ctypes.c_int]
-    l.dib_debug_set_variant.restype = None
+    l.dib_debug_set_tile_order.argtypes = [ctypes.c_int]
+    l.dib_debug_set_tile_order.restype = None
+    l.dib_debug_set_shape.argtypes = [ctypes.c_int]
+    l.dib_debug_set_shape.restype = None
     rs = np.random.RandomState(11)
     imgs, psfs = [], []
-    for sh, sp in zip([(3, 97, 301), (1, 65, 65), (2, 130, 257), (3, 70, 513), (3, 33, 140)], [2, 14, 30, 63, 8]):
+    for sh, sp in zip([(3, 97, 301), (1, 65, 65), (2, 130, 257), (3, 70, 513), (3, 33, 140), (3, 200, 640), (1, 300, 90),
+                       (2, 129, 384), (1, 96, 385)],
+                      [2, 14, 30, 63, 8, 5, 40, 3, 20]):
         imgs.append(rs.random_sample(sh).astype(np.float16))
         a = np.zeros((128, 128), np.float64)
         n = 8 + 4 * sp
@@ -396,18 +401,26 @@ def test_kernel_variants_are_bit_identical():
     O.blur_image_list(want, [{"blurring": True}] * len(imgs), psfs)
     tables = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=True)
     try:
-        for nw, tpw in ((8, 1), (8, 2), (4, 2), (4, 1)):
-            l.dib_debug_set_variant(nw, tpw)
+        for shape, bands in ((0, 1), (1, 1), (1, 0), (0, 1)):
+            l.dib_debug_set_shape(shape)
+            l.dib_debug_set_tile_order(bands)
             outs = blur_ops.sparse_blur([_dev(a) for a in imgs], list(range(len(imgs))), tables)
             for g, w in zip(outs, want):
-                assert np.array_equal(_bits(g.cpu().numpy().squeeze()), _bits(w)), (nw, tpw)
+                assert np.array_equal(_bits(g.cpu().numpy().squeeze()), _bits(w)), (shape, bands)
+        # the fused-multiply-add mode: both shapes agree with each other bit for bit
+        fma = []
+        for shape in (0, 1):
+            l.dib_debug_set_shape(shape)
+            fma.append(blur_ops.sparse_blur([_dev(a) for a in imgs], list(range(len(imgs))), tables, _lib.DIB_ACC_FMA16))
+        for a, b in zip(*fma):
+            assert torch.equal(a, b)
     finally:
-        l.dib_debug_set_variant(4, 1)
+        l.dib_debug_set_shape(0)
+        l.dib_debug_set_tile_order(1)
 
 
 def test_compaction_more_than_one_launch_chunk():
-    """40 PSFs = two compaction launches (32 + 8): list and stacked entry points agree, and the
-    scheduler trailer behind the last table is zeroed without touching any table."""
+    """40 PSFs = two compaction launches (32 + 8): list and stacked entry points agree."""
     from detectinblur_amd import blur_ops
     rs = np.random.RandomState(21)
     psfs = []
@@ -430,4 +443,4 @@ def test_compaction_more_than_one_launch_chunk():
         r, c, w = t_list.taps(k)
         assert np.array_equal(r.numpy(), rr) and np.array_equal(c.numpy(), cc)
         assert np.array_equal((w.numpy() & 0xffff).astype(np.uint16), ww.view(np.uint16))
-    assert int(t_list.buf[-256:].abs().sum()) == 0
+    assert t_list.buf.numel() == 40 * t_list.words
