@@ -157,11 +157,54 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
             o = torch.empty_like(src)
             outs[i] = o
             outs_p[i] = o.data_ptr()
+    _await(tables)
     _lib.check(_lib.lib().dib_sparse_blur(_lib.ptr_array(ins_p), _lib.ptr_array(outs_p), _lib.int_array(Cs),
                                           _lib.int_array(Hs), _lib.int_array(Ws), _lib.int_array(table_index),
                                           n, _DT[dt], tables.buf.data_ptr(), tables.count, tables.K, acc_mode,
                                           _stream(dev)))
     return outs
+
+
+# ---- tap compaction off the critical path -------------------------------------------------------------------
+# The compaction of a batch's PSFs (8 workgroups, ~5 us, a latency chain) depends on nothing but the PSFs.  Run on a
+# side stream as soon as they are on the device, it overlaps whatever the main stream is still doing -- the previous
+# batch's detector in a training loop, the previous batch's blur in bench.py -- and the blur only waits for its
+# event.  Tables made this way carry `.ready`; sparse_blur / expand_boxes wait on it before they read the tables.
+_side_streams = {}
+
+
+def side_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _side_streams:
+        _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return _side_streams[idx]
+
+
+def compact_psfs_ahead(psfs, normalize, after_current=True):
+    """compact_psfs on the device's side stream.  `after_current`: the side stream first waits for the work already
+    queued on the current stream (needed when that work PRODUCES the PSFs, e.g. their host-to-device copy was issued
+    on it); pass False when the PSFs are known to be complete (bench.py's resident PSFs), so that the compaction may
+    overlap kernels still running on the current stream."""
+    first = psfs[0] if isinstance(psfs, (list, tuple)) else psfs
+    _require_cuda(first, "PSF")
+    main = torch.cuda.current_stream(first.device)
+    side = side_stream(first.device)
+    if after_current:
+        side.wait_stream(main)
+    with torch.cuda.stream(side):
+        tabs = compact_psfs(psfs, normalize)
+        tabs.ready = torch.cuda.Event()
+        tabs.ready.record(side)
+    return tabs
+
+
+def _await(tables):
+    """Make the current stream wait for tables compacted on the side stream (no-op otherwise)."""
+    ev = getattr(tables, "ready", None)
+    if ev is not None:
+        cur = torch.cuda.current_stream(tables.buf.device)
+        cur.wait_event(ev)
+        tables.buf.record_stream(cur)      # the buffer came from the side stream's pool
 
 
 # One-entry cache: the engine calls blur_image_list and then expand_targets with the same PSF
@@ -175,8 +218,22 @@ def invalidate_cache():
     _cache.pop("pin", None)
 
 
+def _cache_key(psfs, normalize):
+    return (bool(normalize),) + tuple((p.data_ptr(), p._version, p.dtype, tuple(p.shape)) for p in psfs)
+
+
+def precompact(psfs, normalize=True, after_current=True):
+    """Start the compaction of these PSF tensors on the side stream now and remember the tables: the
+    blur_image_list / expand_targets calls that follow with the same tensors find them (engine.py does this right
+    behind the PSFs' host-to-device copy, while the GPU is still busy with the previous batch)."""
+    tabs = compact_psfs_ahead(psfs, normalize, after_current)
+    _cache["key"], _cache["tables"] = _cache_key(psfs, normalize), tabs
+    _cache["pin"] = list(psfs)
+    return tabs
+
+
 def compact_psfs_cached(psfs, normalize):
-    key = (bool(normalize),) + tuple((p.data_ptr(), p._version, p.dtype, tuple(p.shape)) for p in psfs)
+    key = _cache_key(psfs, normalize)
     if _cache["key"] == key:
         return _cache["tables"]
     tabs = compact_psfs(psfs, normalize)
@@ -191,6 +248,7 @@ def expand_boxes(boxes, tables, index, H, W):
     _require_cuda(boxes, "boxes")
     if boxes.dtype != torch.float32 or boxes.dim() != 2 or boxes.shape[1] != 4 or not boxes.is_contiguous():
         raise ValueError("boxes must be a contiguous [N,4] float32 tensor")
+    _await(tables)
     _lib.check(_lib.lib().dib_expand_boxes(boxes.data_ptr(), boxes.shape[0], tables.ptr(index), H, W, _stream()))
 
 

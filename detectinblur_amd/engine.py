@@ -52,6 +52,13 @@ def _to_device(images_CPU, targets, blur_dicts, device, blurring):
         for i, h in enumerate(halves):
             if psfs_GPU[i] is None:
                 psfs_GPU[i] = h.to(device, non_blocking=True)
+        # tap compaction starts now, on the side stream: it overlaps the image conversion above and whatever the
+        # previous batch still has on the GPU; blur_image_list / expand_targets pick the tables up from the cache
+        blurring = [p for p, bd in zip(psfs_GPU, blur_dicts) if bd["blurring"]]
+        if cuda and blurring and len({tuple(p.shape) for p in blurring}) == 1 and blurring[0].dim() == 2 \
+                and blurring[0].shape[0] in (128, 256):
+            from . import blur_ops
+            blur_ops.precompact(blurring, normalize=True, after_current=True)
         # theta / lambda1 / lambda2: one [3, B] pinned tensor, one copy
         scal = torch.tensor([[bd["theta_rad"] for bd in blur_dicts], [bd["scale_factor_lambda1"] for bd in blur_dicts],
                              [bd["scale_factor_lambda2"] for bd in blur_dicts]], dtype=torch.float16)

@@ -59,11 +59,21 @@ def manual_blur(image_GPU, psf_GPU, add_noise=False, noise_level=0.001, add_bloc
 
 
 def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_level=0.001, add_block=False,
-                    add_jpeg_artifact=False, jpeg_compressor=None, acc_mode=_lib.DIB_ACC_BITEXACT):
+                    add_jpeg_artifact=False, jpeg_compressor=None, acc_mode=_lib.DIB_ACC_BITEXACT, tables=None):
     """In place: images_GPU[i] is replaced by its blurred version when blur_dicts[i]["blurring"].
-    PSFs arrive un-normalised and are divided by their sum here (reference :98).  Returns None."""
+    PSFs arrive un-normalised and are divided by their sum here (reference :98).  Returns None.
+    `tables` (beyond the reference's signature): tap tables of exactly the blurring PSFs, in order, compacted ahead
+    of time with blur_ops.compact_psfs_ahead (normalize=True) -- the compaction then overlaps earlier GPU work."""
     idx = [i for i, bd in enumerate(blur_dicts) if bd["blurring"]]
     if not idx:
+        return None
+    if tables is not None:
+        if tables.count != len(idx) or tables.K != psfs_GPU[idx[0]].shape[0]:
+            raise ValueError("tables do not belong to the blurring PSFs of this batch")
+        _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts, tables)
+        if add_noise or add_block or add_jpeg_artifact:
+            for i in idx:
+                images_GPU[i] = _post_ops(images_GPU[i], add_noise, noise_level, add_block, add_jpeg_artifact, jpeg_compressor)
         return None
     Ks = {psfs_GPU[i].shape[0] for i in idx}
     dts = {psfs_GPU[i].dtype for i in idx}
@@ -83,13 +93,14 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_lev
     return None
 
 
-def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None):
+def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=None):
     K = psfs_GPU[idx[0]].shape[0]
     for i in idx:
         _check_shapes(images_GPU[i], K)
-    psfs = [psfs_GPU[i] if psfs_GPU[i].dtype == images_GPU[i].dtype else psfs_GPU[i].to(images_GPU[i].dtype)
-            for i in idx]
-    tables = blur_ops.compact_psfs_cached(psfs, normalize=True)
+    if tables is None:
+        psfs = [psfs_GPU[i] if psfs_GPU[i].dtype == images_GPU[i].dtype else psfs_GPU[i].to(images_GPU[i].dtype)
+                for i in idx]
+        tables = blur_ops.compact_psfs_cached(psfs, normalize=True)
     # Scheduling hint (optional, host-side, never needed for correctness): `BlurImage` records the PSF's
     # tap count in blur_dict["psf_taps"].  Tiles are dispatched in descriptor order, so handing the
     # images over heaviest first lets the launch end on its cheapest tiles (~4 % at BASELINE shapes).

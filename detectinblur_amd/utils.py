@@ -2,7 +2,7 @@
 
   * expand_targets / fix_bounding_box_squeeze   reference utils.py:360-434  (HIP, one launch/image)
   * get_norm_params                              reference utils.py:219-273  (host tables)
-  * collate_fn, distributed helpers, meters      reference utils.py:474-785  (see utils_dist.py)
+  * collate_fn, distributed helpers, meters      reference utils.py:474-785  (below)
 """
 import numpy as np
 import torch
