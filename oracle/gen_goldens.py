@@ -234,6 +234,73 @@ def gen_warper(ns, store):
     store["warp_feature"] = w(feat, th, 1 / l1, 1 / l2).numpy()
 
 
+def net_transform_inputs():
+    """Two ragged images with boxes, per-image statistics as engine.py passes them (float64 numpy rows)."""
+    g = torch.Generator().manual_seed(4711)
+    imgs = [torch.rand(3, 50, 70, generator=g), torch.rand(3, 60, 45, generator=g)]
+    tgts = [{"boxes": torch.tensor([[3.5, 4.25, 40.0, 44.5], [10.0, 0.0, 69.0, 49.0]]), "labels": torch.tensor([3, 7])},
+            {"boxes": torch.tensor([[1.0, 2.0, 30.5, 59.0]]), "labels": torch.tensor([1])}]
+    means = np.array([[0.485, 0.456, 0.406], [0.485, 0.456, 0.406]])
+    stds = np.array([[0.229, 0.224, 0.225], [0.11716, 0.11548, 0.11734]])
+    return imgs, tgts, means, stds
+
+
+def gen_net_transforms(ns, store):
+    """Reference models/net_transforms.py: normalise -> resize -> batch (+ box rescaling, crop mode, postprocess)."""
+    NT = ref_harness.load_net_transforms()
+    imgs, tgts, means, stds = net_transform_inputs()
+    for tag, training, use_stats in (("train", True, True), ("eval", False, False)):
+        t = NT.GeneralizedRCNNTransform(64, 100, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], training=training)
+        torch.manual_seed(5)
+        il, out = t([i.clone() for i in imgs], [{k: v.clone() for k, v in d.items()} for d in tgts],
+                    newMeans=means if use_stats else None, newSTDs=stds if use_stats else None)
+        store["nt_%s_batch" % tag] = il.tensors.numpy()
+        store["nt_%s_sizes" % tag] = np.array(il.image_sizes)
+        for k, d in enumerate(out):
+            store["nt_%s_boxes%d" % (tag, k)] = d["boxes"].numpy()
+    # an image that already has the target size: scale factor exactly 1
+    t = NT.GeneralizedRCNNTransform(64, 100, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], training=False)
+    one = torch.rand(3, 64, 100, generator=torch.Generator().manual_seed(8))
+    il, _ = t([one.clone()], None)
+    store["nt_unit_batch"] = il.tensors.numpy()
+    # the blur estimator's batcher (engine.py:262-264): crop to the smallest image, floored to a multiple of 32
+    t = NT.GeneralizedRCNNTransform(64, 100, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], crop_images=True)
+    torch.manual_seed(5)
+    il, _ = t([i.clone() for i in imgs], None)
+    store["nt_crop_batch"] = il.tensors.numpy()
+    store["nt_crop_sizes"] = np.array(il.image_sizes)
+    # eval-mode postprocess: boxes back to the original image sizes
+    t = NT.GeneralizedRCNNTransform(64, 100, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], training=False)
+    res = t.postprocess([{"boxes": torch.tensor([[4.0, 8.0, 60.0, 50.0]])}, {"boxes": torch.tensor([[2.0, 2.0, 40.0, 90.0]])}],
+                        [(64, 90), (100, 75)], [(50, 70), (60, 45)])
+    for k, d in enumerate(res):
+        store["nt_post_boxes%d" % k] = d["boxes"].numpy()
+
+
+def postop_input():
+    x = torch.rand(3, 40, 56, generator=torch.Generator().manual_seed(77))
+    delta = torch.zeros(128, 128)
+    delta[63, 63] = 1.0            # manual_blur with this PSF returns its input: what follows is the post-op chain alone
+    return x, delta
+
+
+POSTOP_SEEDS = (0, 1, 3, 5)
+
+
+def gen_postops(ns, store):
+    """Reference models/blur_functions.py:72-81 on the CPU: Gaussian noise + clamp, nearest-neighbour "block"
+    down/up-sampling, each after the reference's own numpy draws (seeded per case)."""
+    x, delta = postop_input()
+    for seed in POSTOP_SEEDS:
+        np.random.seed(seed); torch.manual_seed(seed)
+        store["noise_%d" % seed] = ns.blur_functions.manual_blur(x.clone(), delta, add_noise=True, noise_level=0.01).numpy()
+        np.random.seed(seed); torch.manual_seed(seed)
+        store["block_%d" % seed] = ns.blur_functions.manual_blur(x.clone(), delta, add_block=True).numpy()
+        np.random.seed(seed); torch.manual_seed(seed)
+        store["both_%d" % seed] = ns.blur_functions.manual_blur(x.clone(), delta, add_noise=True, noise_level=0.004, add_block=True).numpy()
+        store["rng_after_%d" % seed] = np.array([np.random.uniform()])      # the draw order leaves numpy's stream here
+
+
 def jpeg_input():
     g = torch.Generator().manual_seed(2024)
     x = torch.rand(2, 3, 32, 48, generator=g)
@@ -373,6 +440,18 @@ def main():
         np.savez_compressed(os.path.join(OUT, "jpeg.npz"), **store)
         print("jpeg", {k: v.shape for k, v in store.items()})
         return
+    if "--only-net-transforms" in sys.argv:
+        store = {}
+        gen_net_transforms(ns, store)
+        np.savez_compressed(os.path.join(OUT, "net_transforms.npz"), **store)
+        print("net_transforms", {k: v.shape for k, v in store.items()})
+        return
+    if "--only-postops" in sys.argv:
+        store = {}
+        gen_postops(ns, store)
+        np.savez_compressed(os.path.join(OUT, "postops.npz"), **store)
+        print("postops", len(store), "arrays; block cases changed:", [int(not np.array_equal(store["block_%d" % k], postop_input()[0].numpy())) for k in POSTOP_SEEDS])
+        return
     if "--only-warper" in sys.argv:
         store = {}
         gen_warper(ns, store)
@@ -390,7 +469,8 @@ def main():
     meta = {"numpy": np.__version__, "torch": torch.__version__}
     gen_psf_store(ns, meta)
     for name, fn in (("traj", gen_trajectories), ("psf", gen_psfs), ("boxes", gen_boxes),
-                     ("norm", gen_norm), ("fft", gen_fft), ("warper", gen_warper), ("jpeg", gen_jpeg), ("coco", gen_coco_eval)):
+                     ("norm", gen_norm), ("fft", gen_fft), ("warper", gen_warper), ("jpeg", gen_jpeg), ("coco", gen_coco_eval),
+                     ("net_transforms", gen_net_transforms), ("postops", gen_postops)):
         store = {}
         fn(ns, store)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)

@@ -89,3 +89,19 @@ def load():
     ns.blur_functions = importlib.import_module("models.blur_functions")
     _loaded["ns"] = ns
     return ns
+
+
+def load_net_transforms():
+    """The reference's models/net_transforms.py (GeneralizedRCNNTransform, resize_boxes).  Its arithmetic is plain
+    torch; torchvision only contributes `_is_tracing()` (False outside ONNX export) and the two-field `ImageList`
+    container, both supplied here."""
+    load()
+    import torchvision                                  # the MagicMock installed by load()
+    torchvision._is_tracing = lambda: False
+
+    class ImageList(object):
+        def __init__(self, tensors, image_sizes):
+            self.tensors, self.image_sizes = tensors, image_sizes
+
+    sys.modules["torchvision.models.detection.image_list"].ImageList = ImageList
+    return importlib.import_module("models.net_transforms")
