@@ -286,3 +286,32 @@ def rasterize_psfs(traj, fractions, canvas=256, center=True, out_n=None, want64=
                                    p64.data_ptr() if want64 else None, p16.data_ptr() if want16 else None,
                                    ws.data_ptr(), _stream()))
     return p64, p16
+
+
+def normalize_pad(images, means, stds, Hp, Wp, channels_last=False):
+    """images: list of 3 x H x W CUDA tensors (float16 or float32, one dtype); means / stds: [B,3] rows (anything
+    numpy can read; rounded to float32 like torch.as_tensor(row, dtype=float32)).  Returns the fp32 batch
+    [B,3,Hp,Wp] (memory format channels_last on request) holding (x - mean) / std inside each image and 0 in the
+    padding: engine.py:107-110 + net_transforms.py:112-121 + :238-247 in one launch."""
+    import ctypes
+    import numpy as np
+    B = len(images)
+    first = images[0]
+    _require_cuda(first, "image")
+    if first.dtype not in _DT:
+        raise TypeError("image dtype %s not supported (float16 / float32)" % first.dtype)
+    keep, ptrs, Hs, Ws = [], [], [], []
+    for img in images:
+        if img.dtype != first.dtype or not img.is_cuda or img.dim() != 3 or img.shape[0] != 3:
+            raise ValueError("normalize_pad needs 3 x H x W CUDA images of one dtype")
+        img = img if img.is_contiguous() else img.contiguous()
+        keep.append(img); ptrs.append(img.data_ptr()); Hs.append(int(img.shape[1])); Ws.append(int(img.shape[2]))
+    m = np.ascontiguousarray(np.asarray(means, dtype=np.float64).reshape(B, 3).astype(np.float32))
+    sd = np.ascontiguousarray(np.asarray(stds, dtype=np.float64).reshape(B, 3).astype(np.float32))
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    out = torch.empty((B, 3, Hp, Wp), dtype=torch.float32, device=first.device, memory_format=fmt)
+    fp = ctypes.POINTER(ctypes.c_float)
+    _lib.check(_lib.lib().dib_normalize_pad(_lib.ptr_array(ptrs), _DT[first.dtype], _lib.int_array(Hs), _lib.int_array(Ws), B,
+                                            m.ctypes.data_as(fp), sd.ctypes.data_as(fp), out.data_ptr(), Hp, Wp,
+                                            int(bool(channels_last)), _stream(first.device)))
+    return out

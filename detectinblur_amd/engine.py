@@ -68,6 +68,18 @@ def _to_device(images_CPU, targets, blur_dicts, device, blurring):
     return images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2
 
 
+def _to_float(images_GPU, model, device):
+    """reference engine.py:107-110: `image.float()` per image (images that took the JPEG round trip come back on the
+    host, transforms.py:492, hence the `.to(device)`).  When the model's input transform has the fused epilogue and
+    every image is a Half tensor on the GPU, the conversion is left to it: float conversion, normalisation and batch
+    padding then happen in one kernel (models/net_transforms.py) instead of one pass each."""
+    m = getattr(model, "module", model)
+    tf = getattr(m, "transform", None)
+    if tf is not None and getattr(tf, "fused", False) and all(i.is_cuda and i.dtype == torch.float16 and i.dim() == 3 for i in images_GPU):
+        return images_GPU
+    return [image.float().to(device) for image in images_GPU]
+
+
 def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=200, writer=None, distributed_mode=False,
                     blur_train=False, early_stop=False, gpu_blur=False, expand_target_boxes=False,
                     use_custom_image_norm=False, add_noise=False, noise_level=0.001, add_block=False,
@@ -96,7 +108,7 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
                                            add_jpeg_artifact=add_jpeg_artifact, jpeg_compressor=jpeg_compressor)
         if expand_target_boxes and blur_train:
             targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU)
-        images_GPU = [image.float().to(device) for image in images_GPU]   # JPEG artefacts come back on the host (transforms.py:492)
+        images_GPU = _to_float(images_GPU, model, device)
         norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 
         loss_dict = model(images_GPU, targets_GPU, thetas=thetas, lambda1s=l1, lambda2s=l2, newMeans=norm_means, newSTDs=norm_stds)
@@ -236,7 +248,7 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                         ann["bbox"] = boxes[k]
                     else:
                         faulty_boxes += 1
-        images_GPU = [image.float().to(device) for image in images_GPU]   # JPEG artefacts come back on the host (transforms.py:492)
+        images_GPU = _to_float(images_GPU, ensemble_models[0] if use_ensemble else model, device)
         norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 
         if use_ensemble:                                                 # reference :354-366

@@ -39,6 +39,10 @@ class GeneralizedRCNNTransform(nn.Module):
         self.crop_images = crop_images
         self.training = training
         self.normalize_images = normalize_images
+        # Fused epilogue (csrc/dib_epilogue.hip): float conversion + normalisation + zero-padded batch in one launch for
+        # CUDA batches that need no resize; bit-identical to the module-by-module path below, which stays the checker
+        # (tests/test_epilogue_gpu.py) and serves every other case.
+        self.fused = True
 
     _stat_cache = {}
 
@@ -63,14 +67,7 @@ class GeneralizedRCNNTransform(nn.Module):
 
     def resize(self, image, target):
         h, w = image.shape[-2:]
-        if self.training:
-            size = float(self.min_size[int(torch.empty(1).uniform_(0.0, float(len(self.min_size))).item())])
-        else:
-            size = float(self.min_size[-1])
-        lo, hi = float(min(h, w)), float(max(h, w))
-        scale = size / lo
-        if hi * scale > self.max_size:
-            scale = self.max_size / hi
+        scale = self._scale(h, w, self._target_size())
         if scale != 1.0:
             image = F.interpolate(image[None], scale_factor=scale, mode="bilinear", recompute_scale_factor=True,
                                   align_corners=False)[0]
@@ -102,10 +99,62 @@ class GeneralizedRCNNTransform(nn.Module):
         fmt = torch.channels_last if getattr(self, "channels_last", False) else torch.contiguous_format
         return torch.empty(shape, dtype=like.dtype, device=like.device, memory_format=fmt).zero_()
 
+    def _target_size(self):
+        """The min-side target of the next image: one draw on torch's CPU generator when training (reference
+        net_transforms.py:141-149, :155-156), the largest scale otherwise."""
+        if self.training:
+            return float(self.min_size[int(torch.empty(1).uniform_(0.0, float(len(self.min_size))).item())])
+        return float(self.min_size[-1])
+
+    def _scale(self, h, w, size):
+        lo, hi = float(min(h, w)), float(max(h, w))
+        scale = size / lo
+        if hi * scale > self.max_size:
+            scale = self.max_size / hi
+        return scale
+
+    def _forward_fused(self, images, targets, newMeans, newSTDs):
+        """None when the batch does not qualify (not on the GPU, mixed dtypes, crop mode, any image that needs a
+        resize); generator draws are consumed either way, exactly as the unfused path would."""
+        if not (self.fused and self.normalize_images and not self.crop_images and images):
+            return None
+        first = images[0]
+        if not (first.is_cuda and first.dtype in (torch.float16, torch.float32)):
+            return None
+        if any(i.dim() != 3 or i.shape[0] != 3 or i.dtype != first.dtype or not i.is_cuda for i in images):
+            return None
+        state = torch.get_rng_state() if self.training else None
+        sizes = [self._target_size() for _ in images]
+        if any(self._scale(int(i.shape[-2]), int(i.shape[-1]), s) != 1.0 for i, s in zip(images, sizes)):
+            if state is not None:
+                torch.set_rng_state(state)        # the unfused path will make these draws itself
+            return None
+        from .. import blur_ops
+        n = len(images)
+        means = newMeans if newMeans is not None else np.tile(np.asarray(self.image_mean, dtype=np.float64), (n, 1))
+        stds = newSTDs if newSTDs is not None else np.tile(np.asarray(self.image_std, dtype=np.float64), (n, 1))
+        hw = [(int(i.shape[-2]), int(i.shape[-1])) for i in images]
+        Hp = int(math.ceil(max(h for h, _ in hw) / 32.0) * 32)
+        Wp = int(math.ceil(max(w for _, w in hw) / 32.0) * 32)
+        batch = blur_ops.normalize_pad(images, means, stds, Hp, Wp, getattr(self, "channels_last", False))
+        if targets is not None:
+            for t, (h, w) in zip(targets, hw):
+                t["boxes"] = resize_boxes(t["boxes"], (h, w), (h, w))
+        return ImageList(batch, hw), targets
+
     def forward(self, images, targets=None, newMeans=None, newSTDs=None):
         images = list(images)
         if targets is not None:
             targets = [dict(t) for t in targets]        # shallow copies: the caller's dicts stay untouched
+        for image in images:
+            if image.dim() != 3:
+                raise ValueError("images is expected to be a list of 3d tensors of shape [C, H, W], got {}".format(image.shape))
+        fused = self._forward_fused(images, targets, newMeans, newSTDs)
+        if fused is not None:
+            return fused
+        # Half images only arrive from engine.py when the fused path was expected to take them: convert as the
+        # reference's engine would have (engine.py:107-110)
+        images = [i.float() if i.dtype == torch.float16 else i for i in images]
         for i, image in enumerate(images):
             if image.dim() != 3:
                 raise ValueError("images is expected to be a list of 3d tensors of shape [C, H, W], got {}".format(image.shape))

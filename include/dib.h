@@ -91,6 +91,20 @@ int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, const int *
                     void *tables_dev, int num_tables, int K, int acc_mode, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fused epilogue of the blur for the detector's input: `.float()` (engine.py:107-110), per-image
+ * `(x - mean) / std` (models/net_transforms.py:112-121, :135-139) and the zero-padded batch
+ * (net_transforms.py:238-247) in one pass, for batches whose images need no resize (scale factor 1).
+ * in_dev: host array of B device pointers to 3 x H[i] x W[i] planar images of `dtype`; mean / std:
+ * host arrays [B][3] (fp32: the values torch.as_tensor(row, dtype=float32) would hold);
+ * out_dev: [B][3][Hp][Wp] fp32, planar (channels_last = 0) or stored channels-last, i.e. as
+ * [B][Hp][Wp][3] (channels_last != 0); Hp >= H[i], Wp >= W[i]; pixels outside an image become 0.
+ * Same arithmetic as the reference (fp32 subtract, IEEE divide): bit-identical results.
+ * ------------------------------------------------------------------------------------- */
+int dib_normalize_pad(const void *const *in_dev, int dtype, const int *H, const int *W, int B,
+                      const float *mean, const float *std, float *out_dev, int Hp, int Wp,
+                      int channels_last, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Box growth and clamping: utils.py:360-392 (`expand_targets`, one image) and utils.py:395-434
  * (`fix_bounding_box_squeeze`).  boxes_dev: [N][4] float32 xyxy, updated in place.
  * ------------------------------------------------------------------------------------- */
