@@ -100,6 +100,7 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
         lr_scheduler = utils.warmup_lr_scheduler(optimizer, min(1000, len(data_loader) - 1), 1.0 / 1000)
 
     iteration_count = 0
+    deferred = None
     for images_CPU, targets, blur_dicts in metric_logger.log_every(data_loader, print_freq, header):
         images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2 = _to_device(images_CPU, targets, blur_dicts, device, blur_train)
         if gpu_blur and blur_train:
@@ -116,29 +117,44 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
 
         loss_dict_reduced = utils.reduce_dict(loss_dict)                 # logging only
         losses_reduced = sum(loss for loss in loss_dict_reduced.values())
-        loss_value = losses_reduced.item()
-        if iteration_count % 500 == 0 and writer is not None and utils.is_main_process() and iteration_count % print_freq == 0:
-            step = iteration_count + epoch * len(data_loader)
-            for key, v in loss_dict_reduced.items():
-                writer.add_scalar("losses/" + key, v, step)
-            writer.add_scalar("losses/overallLoss", loss_value, step)
-            writer.add_scalar("learningRate", optimizer.param_groups[0]["lr"], step)
-        if not math.isfinite(loss_value):                                # reference :145-148
-            print("Loss is {}, stopping training".format(loss_value))
-            print(loss_dict_reduced)
-            sys.exit(1)
 
         optimizer.zero_grad()
         losses.backward()
         optimizer.step()
         if lr_scheduler is not None:
             lr_scheduler.step()
-        metric_logger.update(loss=losses_reduced, **loss_dict_reduced)
-        metric_logger.update(lr=optimizer.param_groups[0]["lr"])
+        # Logging and the finite-loss check read the PREVIOUS step's numbers: those are on the host already, so the
+        # `.item()` never waits, and this step's forward, backward and update were all enqueued before anything is
+        # read.  (The reference reads the current loss between forward and backward, engine.py:131-148: the host then
+        # waits for the forward pass and the GPU idles while the backward pass is issued.)  A non-finite loss still
+        # stops the run, one step later; the last step is checked behind the loop.
+        if deferred is not None:
+            _log_step(*deferred)
+        deferred = (metric_logger, writer, losses_reduced, loss_dict_reduced, optimizer.param_groups[0]["lr"],
+                    iteration_count, epoch, len(data_loader), print_freq)
         if early_stop is not None and early_stop is not False and iteration_count > early_stop:
             break
         iteration_count += 1
+    if deferred is not None:
+        _log_step(*deferred)
     return metric_logger
+
+
+def _log_step(metric_logger, writer, losses_reduced, loss_dict_reduced, lr, iteration_count, epoch, n_iter, print_freq):
+    """reference engine.py:131-158: meters, TensorBoard scalars every 500 iterations, exit on a non-finite loss."""
+    loss_value = losses_reduced.item()
+    if iteration_count % 500 == 0 and writer is not None and utils.is_main_process() and iteration_count % print_freq == 0:
+        step = iteration_count + epoch * n_iter
+        for key, v in loss_dict_reduced.items():
+            writer.add_scalar("losses/" + key, v, step)
+        writer.add_scalar("losses/overallLoss", loss_value, step)
+        writer.add_scalar("learningRate", lr, step)
+    if not math.isfinite(loss_value):                                # reference :145-148
+        print("Loss is {}, stopping training".format(loss_value))
+        print(loss_dict_reduced)
+        sys.exit(1)
+    metric_logger.update(loss=losses_reduced, **loss_dict_reduced)
+    metric_logger.update(lr=lr)
 
 
 # ---- ensemble routing (reference engine.py:171-218) ------------------------------------------------

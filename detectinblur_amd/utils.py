@@ -251,6 +251,8 @@ class SmoothedValue(object):
         return self.deque[-1]
 
     def __str__(self):
+        if not self.deque:          # nothing logged yet (the training loop logs a step once the next one is enqueued)
+            return "-"
         return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
 
 
