@@ -225,6 +225,15 @@ def warper_inputs():
     return x, feat, th, l1, l2
 
 
+def warper_smooth_input():
+    """A low-frequency image (11 x 11 box blur of noise, contrast restored): Half grid coordinates jitter the sampling
+    position by ~1e-2 px, which moves a smooth image by ~1e-3 -- while a warp that is off by a pixel moves it by ~5e-2."""
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(3, 3, 40, 56, generator=g)
+    x = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (5, 5, 5, 5), mode="reflect"), 11, 1)
+    return ((x - x.amin(dim=(1, 2, 3), keepdim=True)) / (x.amax(dim=(1, 2, 3), keepdim=True) - x.amin(dim=(1, 2, 3), keepdim=True))).contiguous()
+
+
 def gen_warper(ns, store):
     """Reference models/warper.py on CPU: image warp and the inverse-scale feature warp."""
     import importlib
@@ -232,6 +241,7 @@ def gen_warper(ns, store):
     x, feat, th, l1, l2 = warper_inputs()
     store["warp_image"] = w(x, th, l1, l2).numpy()
     store["warp_feature"] = w(feat, th, 1 / l1, 1 / l2).numpy()
+    store["warp_smooth"] = w(warper_smooth_input(), th, l1, l2).numpy()
 
 
 def net_transform_inputs():
