@@ -1,5 +1,5 @@
-"""A/B/C of the tiled blur's workgroup shapes inside ONE process (boxes differ by several per cent):
-4 = 256-wide tiles, 4 waves x 8 rows; 8 = 256-wide, 8 waves x 4 rows; 2 = 128-wide ("narrow"), 4 waves x 8 rows."""
+"""A/B of the tiled blur's two tile shapes inside ONE process (boxes differ by several per cent):
+0 = 128 x 32 "narrow" tiles (default), 1 = 256 x 32 tiles."""
 import sys, ctypes
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -11,7 +11,7 @@ tables = blur_ops.compact_psfs(psfs, normalize=True)
 idx = sorted(range(8), key=lambda k: -dicts[k]["psf_taps"])
 ordered = [images[k] for k in idx]
 sets = [ordered] + [[torch.rand(3, 800, 1333, generator=torch.Generator().manual_seed(977 * s + i)).half().to(dev) for i in range(8)] for s in range(1, 6)]
-l = _lib.lib(); l.dib_debug_set_waves.argtypes = [ctypes.c_int]
+l = _lib.lib(); l.dib_debug_set_shape.argtypes = [ctypes.c_int]
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 def timeit(fn, reps=100):
     for k in range(300): fn(k)
@@ -22,8 +22,8 @@ ring = [None] * 6
 def cold(k, mode):
     j = k % 6; ring[j] = None; ring[j] = blur_ops.sparse_blur(list(sets[j]), idx, tables, mode)
 for rep in range(3):
-    for shape in (4, 8, 2):
-        l.dib_debug_set_waves(shape)
+    for shape in (1, 0):
+        l.dib_debug_set_shape(shape)
         w0 = timeit(lambda k: blur_ops.sparse_blur(list(ordered), idx, tables, 0))
         w2 = timeit(lambda k: blur_ops.sparse_blur(list(ordered), idx, tables, 2))
         c0 = timeit(lambda k: cold(k, 0), 102)
