@@ -221,7 +221,7 @@ __device__ __forceinline__ void tap_loop_fp32(float (&acc)[R][4], const unsigned
 
 // Diagnostic stamps (nullptr in every product launch): shader-clock readings of lane 0 of wave 0.
 __device__ __forceinline__ void stamp(unsigned long long *dbg, int slot) {
-  if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+  if (dbg && threadIdx.x == 0) dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = __builtin_readcyclecounter();
 }
 
 // Wave-uniform buffer descriptor of one channel plane (base, byte size): loads and stores then take
@@ -453,15 +453,14 @@ __device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__r
 // contiguous bands, band x of every image forming XCD x's LIST: neighbouring tiles run on one XCD close in time
 // (halo rows hit in L2), and every XCD still gets an equal share of every image, so PSFs of different tap counts do
 // not unbalance the XCDs.  (A performance choice only: any tile order gives the same output.)
-// list_lookup: entry t of list x -> (image, tile index inside the image); false past the end of the list.
-__device__ __forceinline__ bool list_lookup(const BlurBatch &batch, int x, int t, int &img, int &local) {
-  for (int k = 0; k < batch.n; ++k) {
-    const int T = batch.tile_begin[k + 1] - batch.tile_begin[k];
-    const int lo = (x * T) >> 3, hi = ((x + 1) * T) >> 3;
-    if (t < hi - lo) { img = k; local = lo + t; return true; }
-    t -= hi - lo;
-  }
-  return false;
+// Grid: y = image (descriptor order: heaviest first), x = 8 t + list.  The image index comes with the workgroup, so the
+// prologue's chain of dependent scalar loads is descriptor -> table header / first segment (two round trips; a lookup
+// through a flattened tile index cost a third).  band_entry: entry t of list x of an image with T tiles -> tile index
+// inside the image; false past the end of the band (the grid's x extent is 8 x the longest band of the launch).
+__device__ __forceinline__ bool band_entry(int T, int x, int t, int &local) {
+  const int lo = (x * T) >> 3, hi = ((x + 1) * T) >> 3;
+  local = lo + t;
+  return t < hi - lo;
 }
 
 // =============================================================================================================
@@ -634,10 +633,10 @@ __device__ __forceinline__ void blur_narrow_tile_f16(const ImageDesc &d, const i
 template <int ACC>
 __global__ __launch_bounds__(256, 7) void blur_narrow_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K) {
   extern __shared__ unsigned nlds[];
-  int i, local;
-  if (!list_lookup(batch, blockIdx.x & 7, blockIdx.x >> 3, i, local)) return;  // the grid is 8 x the longest list
-  const ImageDesc &d = batch.img[i];
+  const ImageDesc &d = batch.img[blockIdx.y];
   const int per_ch = d.tiles_x * d.tiles_y;
+  int local;
+  if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
   const int ch = local / per_ch;
   local -= ch * per_ch;
   const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
@@ -648,19 +647,15 @@ template <int ACC>
 __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K,
                                                                      unsigned long long *dbg) {
   extern __shared__ uint2 lds[];
-  int i, local;
-  if (batch.xcd_bands) {
-    if (!list_lookup(batch, blockIdx.x & 7, blockIdx.x >> 3, i, local)) return;  // the grid is 8 x the longest list
-  } else {
-    const int tile = blockIdx.x;
-    i = 0;
-#pragma unroll
-    for (int k = 1; k < MAX_BATCH; ++k)
-      if (k < batch.n && tile >= batch.tile_begin[k]) i = k;
-    local = tile - batch.tile_begin[i];
-  }
-  const ImageDesc &d = batch.img[i];
+  const ImageDesc &d = batch.img[blockIdx.y];
   const int per_ch = d.tiles_x * d.tiles_y;
+  int local;
+  if (batch.xcd_bands) {
+    if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
+  } else {
+    local = blockIdx.x;              // flat order (the traffic experiment): tile index = block index
+    if (local >= d.C * per_ch) return;
+  }
   const int ch = local / per_ch;
   local -= ch * per_ch;
   const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
@@ -821,24 +816,27 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     generic.xcd_bands = 0;
     if (dtype == DIB_F16) {
       for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
-      int grid = tiles;
-      if (g_xcd_bands) {   // 8 x the longest per-XCD list (lists differ by at most one tile per image)
-        int longest = 0;
-        for (int x = 0; x < 8; ++x) {
-          int len = 0;
-          for (int k = 0; k < tiled.n; ++k) {
-            const int T = tiled.tile_begin[k + 1] - tiled.tile_begin[k];
-            len += (((x + 1) * T) >> 3) - ((x * T) >> 3);
+      // x extent: the longest image of the launch -- 8 x its longest band, or (flat order) its tile count
+      int gx = 0;
+      for (int k = 0; k < tiled.n; ++k) {
+        const int T = tiled.tile_begin[k + 1] - tiled.tile_begin[k];
+        int ext = T;
+        if (g_xcd_bands || narrow) {
+          int longest = 0;
+          for (int x = 0; x < 8; ++x) {
+            const int len = (((x + 1) * T) >> 3) - ((x * T) >> 3);
+            longest = len > longest ? len : longest;
           }
-          longest = len > longest ? len : longest;
+          ext = 8 * longest;
         }
-        grid = 8 * longest;
+        gx = ext > gx ? ext : gx;
       }
-      if (narrow && acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_FMA16>), dim3(grid), dim3(256), NLDS_BYTES, s, tiled, (const int *)tables_dev, K);
-      else if (narrow) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_BITEXACT>), dim3(grid), dim3(256), NLDS_BYTES, s, tiled, (const int *)tables_dev, K);
-      else if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FP32>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
-      else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FMA16>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
-      else hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_BITEXACT>), dim3(grid), dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      const dim3 grid(gx, tiled.n);
+      if (narrow && acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_FMA16>), grid, dim3(256), NLDS_BYTES, s, tiled, (const int *)tables_dev, K);
+      else if (narrow) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), NLDS_BYTES, s, tiled, (const int *)tables_dev, K);
+      else if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FP32>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FMA16>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
     } else {
       hipLaunchKernelGGL((blur_generic_kernel<float, DIB_ACC_BITEXACT>), dim3(gblocks), dim3(256), 0, s, generic, (const int *)tables_dev, K);
     }
