@@ -93,7 +93,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.dib_abi_version() != 2:
+        if l.dib_abi_version() != 3:
             raise ImportError("libdib_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -55,10 +55,11 @@ class TapTables:
         t = self.buf[off:off + 4 * nseg].cpu().view(-1, 4).tolist()
         return [(a, b, c >> 8, c & 255, d >> 8, d & 255) for a, b, c, d in t]
 
-    def ltaps(self, i):
-        """per-tap (lds_byte_offset, weight_bits) of table i -- tests only."""
+    def ltaps(self, i, quad=False):
+        """per-tap (lds_byte_offset, weight_bits) of table i, for the 96-word window rows of the 256-wide tiles or
+        (quad) the 56-element rows of the default 128-wide tiles -- tests only."""
         n = self.header(i)[0]
-        off = i * self.words + ((8 + self.K + 1 + 3) & ~3) + 6 * self.K * self.K
+        off = i * self.words + ((8 + self.K + 1 + 3) & ~3) + 6 * self.K * self.K + (self.K * self.K + 8 if quad else 0)
         t = self.buf[off:off + n].cpu()
         return t & 0xffff, (t >> 16) & 0xffff
 

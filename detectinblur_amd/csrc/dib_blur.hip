@@ -33,6 +33,7 @@
 #include "dib_common.h"
 #include <hip/hip_fp16.h>
 #include <mutex>
+#include <stdlib.h>
 
 namespace dib {
 
@@ -630,9 +631,243 @@ __device__ __forceinline__ void blur_narrow_tile_f16(const ImageDesc &d, const i
   }
 }
 
+// =============================================================================================
+// "Quad" shape: 128-wide tiles like the narrow shape, but a lane owns FOUR columns of FOUR rows --
+// lane = 32 h + j computes columns {j, j+32, j+64, j+96} of rows 4h .. 4h+3 of its wave's 8 rows -- and the
+// window is stored as 8-byte elements  e[k] = {P[k], P[k+32] | P[k+64], P[k+96]}  (k = 0 .. 31 + SEG_COLS),
+// so that one tap is 4 x ds_read_b64 per lane instead of 8 x ds_read_b32: the LDS serves 256 B per clock for
+// 8-byte reads and 128 B for 4-byte ones (MI355X_MICROARCH.md, LDS table), and the narrow shape's tap phase ran at
+// the LDS's rate, not the vector ALU's (16 LDS cycles against ~42 ALU cycles per wave-tap, four SIMDs sharing one LDS).
+// Element k + dcol is 8-byte aligned for every tap column, and the 32 lanes of an LDS lane group read 32
+// consecutive elements = all 64 banks once.  44 rows x 56 elements x 8 B = 19,712 B: eight workgroups per CU.
+// =============================================================================================
+constexpr int QTILE_W = 128;
+constexpr int QPITCH = QUAD_PITCH * 8;        // bytes per LDS row (448)
+constexpr int QLDS_BYTES = LROWS * QPITCH;    // 19,712 B
+static_assert(QPITCH == 448, "the asm below hard-codes the LDS row pitch");
+static_assert(LROWS % NW == 0, "every wave fills the same number of window rows");
+
+// The tap loop of the narrow shape with 4 x 8-byte reads: rows i = 0..3 of the tap land in v[base+2i : base+2i+1] =
+// the operands of accumulators 2i (columns j, j+32) and 2i+1 (columns j+64, j+96).  The LDS address is one
+// v_mad_u32_u16 (low 16 bits of the ltap word + lane base).  Operands as in tap_loop_narrow.
+#define DIBQ_READ(base)                                                                                      \
+  "v_mad_u32_u16 v48, %11, 1, %15\n\t"                                                                        \
+  "ds_read_b64 v[" #base ":" #base "+1], v48\n\tds_read_b64 v[" #base "+2:" #base "+3], v48 offset:448\n\t"    \
+  "ds_read_b64 v[" #base "+4:" #base "+5], v48 offset:896\n\tds_read_b64 v[" #base "+6:" #base "+7], v48 offset:1344\n\t"
+#ifdef DIBQ_SENS   // scratch: sensitivity of the launch time to 4 more instructions of one kind per tap (never in the product build)
+#if DIBQ_SENS == 1
+#define DIBQ_PAD(b) "s_mov_b32 %13, %13\n\ts_mov_b32 %13, %13\n\ts_mov_b32 %13, %13\n\ts_mov_b32 %13, %13\n\t"
+#elif DIBQ_SENS == 2
+#define DIBQ_PAD(b) "v_mov_b32 v48, v48\n\tv_mov_b32 v48, v48\n\tv_mov_b32 v48, v48\n\tv_mov_b32 v48, v48\n\t"
+#elif DIBQ_SENS == 3
+#define DIBQ_PAD(b) "ds_read_b64 v[" #b ":" #b "+1], v48\n\tds_read_b64 v[" #b ":" #b "+1], v48\n\tds_read_b64 v[" #b ":" #b "+1], v48\n\tds_read_b64 v[" #b ":" #b "+1], v48\n\t"
+#else
+#define DIBQ_PAD(b)
+#endif
+#else
+#define DIBQ_PAD(b)
+#endif
+template <bool FUSED>
+__device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
+  unsigned sA, sB, sC, st;
+  unsigned a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
+#define DIB_RQ_ASM(ARITH_A, ARITH_B) \
+  asm volatile( \
+      "s_load_dword %11, %14, %8\n\ts_add_u32 %8, %8, 4\n\t" DIBN_NEXTTAP \
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIBQ_READ(32) \
+      "Ldibq_loop%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
+      DIBQ_READ(40) DIBQ_PAD(40) DIBN_NEXTTAP \
+      ARITH_A \
+      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 Ldibq_done%=\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
+      DIBQ_READ(32) DIBQ_PAD(32) DIBN_NEXTTAP \
+      ARITH_B \
+      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc0 Ldibq_loop%=\n\t" \
+      "Ldibq_done%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)" \
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+s"(toff), "+s"(cnt), \
+        "=&s"(sA), "=&s"(sB), "=&s"(sC), "=&s"(st) \
+      : "s"(ltaps), "v"(lane_addr) \
+      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "scc", \
+        "memory")
+  if constexpr (FUSED) { DIB_RQ_ASM(DIBN_FMADD_A, DIBN_FMADD_B); } else { DIB_RQ_ASM(DIBN_MADD_A, DIBN_MADD_B); }
+#undef DIB_RQ_ASM
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
+}
+
+// {lo, hi} 16-bit values -> one dword.  As asm because hipcc zero-extends a 16-bit buffer load's result with a v_and
+// before any 32-bit use (the hardware already did), even when the user is v_perm_b32, which never looks at those bits:
+// a 16-bit asm operand is passed any-extended.
+__device__ __forceinline__ unsigned pack_lo16(short hi, short lo) {
+  unsigned r;
+  asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(0x05040100u));
+  return r;
+}
+
 template <int ACC>
-__global__ __launch_bounds__(256, 7) void blur_narrow_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K) {
+__device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
+                                                   unsigned *lds) {
+#pragma clang fp contract(off)
+  constexpr int GQ = LROWS / NW;              // LDS rows a wave fills (11)
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int H = d.H, W = d.W, w2 = W * 2;
+  const int mode = pad_mode_for(K, H, W);
+  const int pb = K / 2 - 1, pa = K / 2;
+  const int nsegs = tab[HDR_NSEGS];
+  const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
+  const unsigned long long la = (unsigned long long)(tab + table_ltaps_q_off(K));
+  const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
+  const int x0 = tx * QTILE_W, y0 = ty * TH;
+  const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(d.in, ch, H, W);
+  h2 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = h2{0, 0};
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+  const int qb = wave * GQ;
+  // Lane-derived values of the later phases are recomputed there from an opaque copy of the lane index (2-3 instructions):
+  // hoisted to here they would stay live across the 44 outstanding window loads and spill (64 registers = 8 waves / SIMD).
+  // (the lane index itself comes from v_mbcnt: no input register to keep either)
+  auto fresh_lane = [&]() { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; };
+  typedef unsigned lds_u2v __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) lds_u2v lds_u2;
+
+  for (int sg = 0; sg < nsegs; ++sg) {
+    const Window w = window_of(segs[sg]);
+    const int lane = fresh_lane();
+    // ---- fill: per LDS row the four values P[lane + 32 m] of element `lane` ----------------------------------------
+    short v[GQ][4];
+    unsigned coff[4];
+    int soff[GQ];
+    unsigned zmask = 0;
+    const int c_first = x0 + pb - w.cmax, r_first = y0 + pb - w.rl;
+    const bool zero_mode = mode == PAD_ZERO;
+    if (!zero_mode && c_first >= 0 && c_first + 63 + 96 <= W - 1) {
+      const unsigned c0 = 2u * (unsigned)(c_first + lane);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) coff[k] = c0 + 64u * k;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bool z;
+        coff[k] = 2u * (unsigned)map_coord_sel(c_first + lane + 32 * k, W, pa, pb, mode, z);
+        zmask |= z ? 1u << k : 0u;
+      }
+    }
+    if (!zero_mode && r_first >= 0 && r_first + LROWS - 1 <= H - 1) {
+      const int s0 = (r_first + qb) * w2;
+#pragma unroll
+      for (int g = 0; g < GQ; ++g) soff[g] = s0 + g * w2;
+    } else {
+      const int nrows = TH + (w.rl - w.rf);
+#pragma unroll
+      for (int g = 0; g < GQ; ++g) {
+        bool zr;
+        const int sr = map_coord_sel(r_first + min(qb + g, nrows - 1), H, pa, pb, mode, zr);
+        zmask |= zr ? 1u << (8 + g) : 0u;
+        soff[g] = sr * w2;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) {
+      const int so = __builtin_amdgcn_readfirstlane(soff[g]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
+    }
+#if defined(DIBQ_SENS) && DIBQ_SENS == 4   // +11 window loads per fill
+    {
+      short dummy[GQ];
+#pragma unroll
+      for (int g = 0; g < GQ; ++g) dummy[g] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[0] + 2u, __builtin_amdgcn_readfirstlane(soff[g]), 0);
+#pragma unroll
+      for (int g = 0; g < GQ; ++g) asm volatile("" :: "v"(dummy[g]));
+    }
+#endif
+    if (sg > 0) __syncthreads();  // every wave is done reading the previous window
+    // Elements 0 .. 31 + column extent are read by the taps; writing all 56 of a row costs the same (an LDS store is
+    // priced per instruction), lanes 56-63 own no element.  The two 16-bit values of a word are merged by v_perm_b32
+    // straight from the load registers (the packing does not care what their high halves hold).
+    const bool masked = __builtin_amdgcn_ballot_w64(zmask != 0) != 0;   // PAD_ZERO images only
+    const int wl = fresh_lane();
+    const unsigned wp = lds0 + (unsigned)(qb * QPITCH + wl * 8);
+    if (wl < QUAD_PITCH) {
+      if (!masked) {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+          lds_u2v e;
+          typedef short s2v __attribute__((ext_vector_type(2)));
+          e.x = __builtin_bit_cast(unsigned, s2v{v[g][0], v[g][1]});
+          e.y = __builtin_bit_cast(unsigned, s2v{v[g][2], v[g][3]});
+          *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+          unsigned u[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            u[k] = (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u)) ? 0u : (unsigned)(unsigned short)v[g][k];
+          lds_u2v e;
+          e.x = u[0] | (u[1] << 16);
+          e.y = u[2] | (u[3] << 16);
+          *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
+        }
+      }
+    }
+    __syncthreads();
+    const int tl = fresh_lane();
+    const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
+    tap_loop_quad<ACC == DIB_ACC_FMA16>(acc, ltaps, w.t0, w.n, lane_addr);
+  }
+  // ---- store: a store instruction writes 32 columns of row y (lanes 0-31) and of row y + 4 (lanes 32-63); lanes
+  // outside the image get an out-of-range buffer offset and are dropped by the range check ----------------------------
+  {
+    const __amdgpu_buffer_rsrc_t out_rsrc = plane_rsrc(d.out, ch, H, W);
+    const int sl = fresh_lane();
+    const int yl = y0 + wave * 8 + (sl >> 5) * 4, xl = x0 + (sl & 31);
+    const unsigned base = (unsigned)(yl * w2 + xl * 2), oob = 0x7ffffff0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool row_ok = yl + i < H;
+      const unsigned a0 = __builtin_bit_cast(unsigned, acc[2 * i]), a1 = __builtin_bit_cast(unsigned, acc[2 * i + 1]);
+      const unsigned ro = base + (unsigned)(i * w2);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a0 & 0xffffu), out_rsrc, row_ok && xl < W ? ro : oob, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a0 >> 16), out_rsrc, row_ok && xl + 32 < W ? ro + 64u : oob, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a1 & 0xffffu), out_rsrc, row_ok && xl + 64 < W ? ro + 128u : oob, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a1 >> 16), out_rsrc, row_ok && xl + 96 < W ? ro + 192u : oob, 0, 0);
+#if defined(DIBQ_SENS) && DIBQ_SENS == 5   // +8 stores per wave (the same bytes again)
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a0 & 0xffffu), out_rsrc, row_ok && xl < W ? ro : oob, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a1 & 0xffffu), out_rsrc, row_ok && xl + 64 < W ? ro + 128u : oob, 0, 0);
+#endif
+    }
+  }
+}
+
+#ifdef DIB_TIMELINE
+// scratch/timeline.py: per-workgroup residency (100 MHz wall clock) + where it ran; never defined in the product build.
+// The begin stamp and the record index wait in 16 extra bytes of LDS and the buffer pointer is a device global read (volatile) at the end, so
+// that no value stays live across the tile function: a few more live SGPRs push the allocation from 80 to 96 (+16 for the trap
+// handler's) and cost a wave per SIMD, and the measurement would not be of the shipped kernel.
+__device__ unsigned long long *g_timeline;
+#define DIB_TL_SLOT (*(unsigned long long *volatile *)&g_timeline)
+constexpr int TL_WORD = (QLDS_BYTES > NLDS_BYTES ? QLDS_BYTES : NLDS_BYTES) / 4;
+#else
+#endif
+
+template <int ACC, bool QUAD>
+__global__ __launch_bounds__(256, 8) void blur_narrow_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K) {
   extern __shared__ unsigned nlds[];
+#ifdef DIB_TIMELINE
+  if (threadIdx.x == 0) {   // 16 more bytes of LDS
+    *(unsigned long long *)(nlds + TL_WORD) = __builtin_amdgcn_s_memrealtime();
+    nlds[TL_WORD + 2] = blockIdx.y * 1024 + blockIdx.x;   // x extent of the BASELINE launch: 832
+  }
+#endif
   const ImageDesc &d = batch.img[blockIdx.y];
   const int per_ch = d.tiles_x * d.tiles_y;
   int local;
@@ -640,7 +875,20 @@ __global__ __launch_bounds__(256, 7) void blur_narrow_f16_kernel(BlurBatch batch
   const int ch = local / per_ch;
   local -= ch * per_ch;
   const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
-  blur_narrow_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, nlds);
+  if constexpr (QUAD) blur_quad_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, nlds);
+  else blur_narrow_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, nlds);
+#ifdef DIB_TIMELINE
+  if (threadIdx.x == 0) {
+    unsigned long long *tl = DIB_TL_SLOT;
+    if (tl) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long *o = tl + 4 * (size_t)*(volatile unsigned *)(nlds + TL_WORD + 2);
+      o[0] = *(volatile unsigned long long *)(nlds + TL_WORD);
+      o[1] = __builtin_amdgcn_s_memrealtime();
+      o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+  }
+#endif
 }
 
 template <int ACC>
@@ -720,14 +968,28 @@ using namespace dib;
 
 // Diagnostics only: when set, the tiled kernel records per-workgroup phase stamps (8 x u64 each).
 static unsigned long long *g_stamp_buffer = nullptr;
-extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) { g_stamp_buffer = (unsigned long long *)dev_ptr; }
+extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) {
+  g_stamp_buffer = (unsigned long long *)dev_ptr;
+#ifdef DIB_TIMELINE
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(dib::g_timeline), &g_stamp_buffer, sizeof(g_stamp_buffer));
+#endif
+}
+#ifdef DIB_TIMELINE
+#define TL_EXTRA 16
+#else
+#define TL_EXTRA 0
+#endif
 // Tile order of the tiled kernel: 1 = per-XCD bands (default), 0 = flat (the traffic experiment of DESIGN.md section 4).
 static int g_xcd_bands = 1;
-// Tile shape serving fp16 images in the bit-exact and FMA16 modes (both shapes bit-identical; tests/test_blur_gpu.py
-// compares them): 0 = 128 x 32 "narrow" tiles, 8 workgroups per CU (default), 1 = 256 x 32 tiles, 4 per CU (also what
-// DIB_ACC_FP32 runs on).
-static int g_shape = 0;
-extern "C" void dib_debug_set_shape(int shape) { g_shape = shape == 1 ? 1 : 0; }
+// Tile shape serving fp16 images in the bit-exact and FMA16 modes (all shapes bit-identical; tests/test_blur_gpu.py
+// compares them): 0 = 128 x 32 "quad" tiles (8-byte LDS elements), 8 workgroups per CU (default), 1 = 256 x 32 tiles,
+// 4 per CU (also what DIB_ACC_FP32 runs on), 2 = 128 x 32 "narrow" tiles (4-byte LDS words; round 2's first default).
+static int shape_from_env() {   // DIB_BLUR_SHAPE=0|1|2 runs a whole test suite on one shape
+  const char *e = getenv("DIB_BLUR_SHAPE");
+  return e && e[0] >= '0' && e[0] <= '2' && !e[1] ? e[0] - '0' : 0;
+}
+static int g_shape = shape_from_env();
+extern "C" void dib_debug_set_shape(int shape) { g_shape = shape >= 0 && shape <= 2 ? shape : 0; }
 extern "C" void dib_debug_set_tile_order(int xcd_bands) { g_xcd_bands = xcd_bands ? 1 : 0; }
 
 namespace {
@@ -751,8 +1013,10 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_BITEXACT>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FP32>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FMA16>, LDS_BYTES));
-    DIB_HIP_CHECK(opt_in(blur_narrow_f16_kernel<DIB_ACC_BITEXACT>, NLDS_BYTES));
-    DIB_HIP_CHECK(opt_in(blur_narrow_f16_kernel<DIB_ACC_FMA16>, NLDS_BYTES));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, false>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, true>), QLDS_BYTES + TL_EXTRA));
     st.ready = true;
   }
   return DIB_OK;
@@ -791,7 +1055,8 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   int i = 0;
   while (i < B) {
     BlurBatch tiled, generic;
-    const bool narrow = g_shape == 0 && dtype == DIB_F16 && acc_mode != DIB_ACC_FP32;
+    const bool narrow = g_shape != 1 && dtype == DIB_F16 && acc_mode != DIB_ACC_FP32;   // either 128-wide shape
+    const bool quad = narrow && g_shape == 0;
     tiled.n = generic.n = 0;
     int tiles = 0, gblocks = 0;
     for (; i < B && tiled.n < MAX_BATCH; ++i) {
@@ -832,8 +1097,10 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
         gx = ext > gx ? ext : gx;
       }
       const dim3 grid(gx, tiled.n);
-      if (narrow && acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_FMA16>), grid, dim3(256), NLDS_BYTES, s, tiled, (const int *)tables_dev, K);
-      else if (narrow) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), NLDS_BYTES, s, tiled, (const int *)tables_dev, K);
+      if (quad && acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_FMA16, true>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, (const int *)tables_dev, K);
+      else if (quad) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, (const int *)tables_dev, K);
+      else if (narrow && acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_FMA16, false>), grid, dim3(256), NLDS_BYTES + TL_EXTRA, s, tiled, (const int *)tables_dev, K);
+      else if (narrow) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false>), grid, dim3(256), NLDS_BYTES + TL_EXTRA, s, tiled, (const int *)tables_dev, K);
       else if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FP32>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FMA16>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);

@@ -16,17 +16,21 @@ constexpr int HDR_NTAPS = 0, HDR_RMIN = 1, HDR_RMAX = 2, HDR_CMIN = 3, HDR_CMAX 
 // box spans at most SEG_ROWS+1 PSF rows and SEG_COLS+1 PSF columns: the unit the tiled blur stages
 // in LDS.  Entry = uint4 {first tap, end tap, (r_first << 8) | r_last, (cmin << 8) | cmax}.
 constexpr int HDR_NSEGS = 7;
-constexpr int SEG_ROWS = 16, SEG_COLS = 32;
+constexpr int SEG_ROWS = 12, SEG_COLS = 24;
 // LDS window geometry of the tiled blur (dib_blur.hip), needed here because the compaction kernel
-// pre-computes, per tap, the byte offset of its source word inside that window:
-//   ltap = ((r_last - r) * WIN_PITCH + (cmax - c)) * 8   |   fp16 weight bits << 16
-constexpr int WIN_PITCH = 64 + SEG_COLS;  // 8-byte words per LDS window row
+// pre-computes, per tap, the byte offset of its source word inside that window, once per window layout:
+//   ltap   = ((r_last - r) * WIN_PITCH  + (cmax - c)) * 8   |   fp16 weight bits << 16     256- and 128-wide tiles
+//   ltap_q = ((r_last - r) * QUAD_PITCH + (cmax - c)) * 8   |   fp16 weight bits << 16     128-wide "quad" tiles
+constexpr int WIN_PITCH = 96;              // 8-byte words per LDS window row (64 + SEG_COLS are used)
+constexpr int QUAD_PITCH = 32 + SEG_COLS;  // 8-byte elements {P[k], P[k+32], P[k+64], P[k+96]} per LDS window row (56)
+static_assert(WIN_PITCH >= 64 + SEG_COLS, "window row too short for a segment");
 
 __host__ __device__ inline int table_rowptr_off() { return HDR_WORDS; }
 __host__ __device__ inline int table_taps_off(int K) { return (HDR_WORDS + K + 1 + 3) & ~3; }
 __host__ __device__ inline int table_segs_off(int K) { return table_taps_off(K) + 2 * K * K; }
 __host__ __device__ inline int table_ltaps_off(int K) { return table_segs_off(K) + 4 * K * K; }
-__host__ __device__ inline int table_words(int K) { return table_ltaps_off(K) + K * K + 8; }
+__host__ __device__ inline int table_ltaps_q_off(int K) { return table_ltaps_off(K) + K * K + 8; }
+__host__ __device__ inline int table_words(int K) { return table_ltaps_q_off(K) + K * K + 8; }
 
 // ---- padding modes of manual_blur (models/blur_functions.py:28-31, :55-58) ---------------
 enum PadMode { PAD_REFLECT = 0, PAD_ZERO = 1, PAD_REPLICATE = 2 };

@@ -349,6 +349,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   // ---- segmentation (wave 0): greedy runs with row span <= SEG_ROWS and column span <= SEG_COLS --------
   uint4 *segs = reinterpret_cast<uint4 *>(tab + table_segs_off(K));
   unsigned *ltaps = reinterpret_cast<unsigned *>(tab + table_ltaps_off(K));
+  unsigned *ltaps_q = reinterpret_cast<unsigned *>(tab + table_ltaps_q_off(K));
   // per-tap LDS offsets of a closed segment [s0, s1) with last row rl and last column cmx
   auto emit_ltaps = [&](int s0, int s1, int rl, int cmx) {
     for (int j = s0 + lane; j < s1; j += 64) {
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
       else { const uint2 tp = taps[j]; rcj = tp.x & 0xffffu; wj = tp.y & 0xffffu; }
       const int rj = rcj >> 8, cj = rcj & 255;
       ltaps[j] = (unsigned)(((rl - rj) * WIN_PITCH + (cmx - cj)) * 8) | (wj << 16);
+      ltaps_q[j] = (unsigned)(((rl - rj) * QUAD_PITCH + (cmx - cj)) * 8) | (wj << 16);
     }
   };
   int nseg = 0, seg_start = 0, seg_r0 = 0, seg_rlast = 0, car_cmin = 1 << 20, car_cmax = -1;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
     emit_ltaps(seg_start, ntaps, seg_rlast, car_cmax);
     ++nseg;
   }
-  if (lane < 8) ltaps[ntaps + lane] = 0;  // the blur's scalar prefetch runs up to two taps past the end
+  if (lane < 8) ltaps[ntaps + lane] = ltaps_q[ntaps + lane] = 0;  // the blur's scalar prefetch runs up to two taps past the end
   if (lane == 0) tab[HDR_NSEGS] = nseg;
 }
 

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 2 /* 2: tap-table buffers carry no scheduler trailer any more */
+#define DIB_ABI_VERSION 3 /* 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+                             per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
 #define DIB_OK 0
@@ -55,9 +56,10 @@ const char *dib_last_error(void);
  * Layout (int32 words): [0]=ntaps [1]=rmin [2]=rmax [3]=cmin [4]=cmax [5]=K [6]=sum bits
  * [7]=nsegs | rowptr[K+1] | pad to x4 | taps[K*K] as {uint32 (row<<8|col), uint32 weight bits}
  * | segments[K*K] as {first tap, end tap, r_first<<8|r_last, cmin<<8|cmax} (runs of consecutive
- * taps with a bounding box of at most 17 rows x 33 columns: the unit staged in LDS by the blur)
+ * taps with a bounding box of at most 13 rows x 25 columns: the unit staged in LDS by the blur)
  * | ltaps[K*K+8] one word per tap: byte offset of its source word in the blur's LDS window (low
- * 16 bits) and the fp16 weight bits (high 16 bits).
+ * 16 bits) and the fp16 weight bits (high 16 bits) | ltaps_q[K*K+8] the same for the window layout
+ * of the default 128-wide tiles (8-byte elements {P[k], P[k+32], P[k+64], P[k+96]}).
  * ------------------------------------------------------------------------------------- */
 size_t dib_tap_table_bytes(int K); /* bytes of ONE table; K is 128 or 256 */
 /* bytes of the buffer dib_psf_compact fills for B PSFs: B tables, dib_tap_table_bytes(K) apart */

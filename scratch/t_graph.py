@@ -1,0 +1,42 @@
+"""Does a HIP graph of G bench steps (compaction + blur each), alternating between two captured streams, overlap the
+tail of one blur with the compaction / ramp of the next?   python scratch/t_graph.py [G]"""
+import sys, time
+sys.path.insert(0, '.')
+import torch
+import bench
+from detectinblur_amd import blur_ops
+from detectinblur_amd.models import blur_functions as BF
+dev = torch.device("cuda", 0)
+images, dicts, psfs, psfs_host, _ = bench.make_workload(0, dev)
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+def step():
+    blur_ops.invalidate_cache()
+    batch = list(images)
+    BF.blur_image_list(batch, dicts, psfs)
+    return batch
+for _ in range(300): step()
+torch.cuda.synchronize()
+def timeit(fn, n):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
+print("eager step: %.2f us" % timeit(step, 2000))
+ref = [b.clone() for b in step()]
+for nstreams in (1, 2, 3):
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    g = torch.cuda.CUDAGraph()
+    keep = []
+    with torch.cuda.graph(g, stream=streams[0]):
+        fork = torch.cuda.Event(); fork.record(streams[0])
+        for s in streams[1:]: s.wait_event(fork)
+        for i in range(G):
+            with torch.cuda.stream(streams[i % nstreams]):
+                keep.append(step())
+        for s in streams[1:]:
+            j = torch.cuda.Event(); j.record(s); streams[0].wait_event(j)
+    for _ in range(20): g.replay()
+    torch.cuda.synchronize()
+    ok = all(torch.equal(a, b) for out in keep for a, b in zip(out, ref))
+    t = timeit(g.replay, 200) / G
+    print("graph of %d steps on %d stream(s): %.2f us per step, outputs identical: %s" % (G, nstreams, t, ok))
+    del g, keep

@@ -326,7 +326,7 @@ def test_acc_fp32_mode_full_size_batch():
 
 
 def test_segments_cover_taps_in_order_and_are_bounded():
-    """The tap list is cut into consecutive segments of at most 17 rows x 33 columns."""
+    """The tap list is cut into consecutive segments of at most 13 rows x 25 columns (SEG_ROWS + 1, SEG_COLS + 1)."""
     from detectinblur_amd import blur_ops
     rs = np.random.RandomState(77)
     psfs = []
@@ -346,12 +346,12 @@ def test_segments_cover_taps_in_order_and_are_bounded():
         assert segs[0][0] == 0 and segs[-1][1] == len(rr)
         for (s0, s1, rf, rl, cmn, cmx), nxt in zip(segs, segs[1:] + [None]):
             assert s1 > s0
-            assert (rf, rl) == (rr[s0], rr[s1 - 1]) and rl - rf <= 16
-            assert (cmn, cmx) == (cc[s0:s1].min(), cc[s0:s1].max()) and cmx - cmn <= 32
+            assert (rf, rl) == (rr[s0], rr[s1 - 1]) and rl - rf <= 12
+            assert (cmn, cmx) == (cc[s0:s1].min(), cc[s0:s1].max()) and cmx - cmn <= 24
             if nxt is not None:
                 assert nxt[0] == s1
                 # greedy: the next tap could not have joined this segment
-                assert rr[s1] - rf > 16 or max(cmx, cc[s1]) - min(cmn, cc[s1]) > 32
+                assert rr[s1] - rf > 12 or max(cmx, cc[s1]) - min(cmn, cc[s1]) > 24
 
 
 def test_repeated_full_size_batches_are_deterministic(golden):
@@ -401,19 +401,19 @@ def test_tile_shapes_and_orders_are_bit_identical():
     O.blur_image_list(want, [{"blurring": True}] * len(imgs), psfs)
     tables = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=True)
     try:
-        for shape, bands in ((0, 1), (1, 1), (1, 0), (0, 1)):
+        for shape, bands in ((2, 1), (1, 1), (1, 0), (0, 1)):
             l.dib_debug_set_shape(shape)
             l.dib_debug_set_tile_order(bands)
             outs = blur_ops.sparse_blur([_dev(a) for a in imgs], list(range(len(imgs))), tables)
             for g, w in zip(outs, want):
                 assert np.array_equal(_bits(g.cpu().numpy().squeeze()), _bits(w)), (shape, bands)
-        # the fused-multiply-add mode: both shapes agree with each other bit for bit
+        # the fused-multiply-add mode: the shapes agree with each other bit for bit
         fma = []
-        for shape in (0, 1):
+        for shape in (0, 1, 2):
             l.dib_debug_set_shape(shape)
             fma.append(blur_ops.sparse_blur([_dev(a) for a in imgs], list(range(len(imgs))), tables, _lib.DIB_ACC_FMA16))
-        for a, b in zip(*fma):
-            assert torch.equal(a, b)
+        for a, b, c in zip(*fma):
+            assert torch.equal(a, b) and torch.equal(a, c)
     finally:
         l.dib_debug_set_shape(0)
         l.dib_debug_set_tile_order(1)
@@ -438,6 +438,11 @@ def test_compaction_more_than_one_launch_chunk():
         assert t_list.segments(k) == t_stack.segments(k)
         for a, b in zip(t_list.ltaps(k), t_stack.ltaps(k)):
             assert torch.equal(a, b)
+        for a, b in zip(t_list.ltaps(k, quad=True), t_stack.ltaps(k, quad=True)):
+            assert torch.equal(a, b)
+        # both offset arrays describe the same taps: (row distance, column distance) from the segment's last row / column
+        wide, quad = t_list.ltaps(k)[0].numpy(), t_list.ltaps(k, quad=True)[0].numpy()
+        assert np.array_equal(wide // 8 // 96, quad // 8 // 56) and np.array_equal(wide // 8 % 96, quad // 8 % 56)
     for k in (0, 31, 32, 39):
         rr, cc, ww = O.taps_of(O.normalize_psf(psfs[k]))
         r, c, w = t_list.taps(k)
