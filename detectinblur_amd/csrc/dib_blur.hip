@@ -647,54 +647,61 @@ constexpr int QLDS_BYTES = LROWS * QPITCH;    // 19,712 B
 static_assert(QPITCH == 448, "the asm below hard-codes the LDS row pitch");
 static_assert(LROWS % NW == 0, "every wave fills the same number of window rows");
 
-// The tap loop of the narrow shape with 4 x 8-byte reads: rows i = 0..3 of the tap land in v[base+2i : base+2i+1] =
-// the operands of accumulators 2i (columns j, j+32) and 2i+1 (columns j+64, j+96).  The LDS address is one
-// v_mad_u32_u16 (low 16 bits of the ltap word + lane base).  Operands as in tap_loop_narrow.
-#define DIBQ_READ(base)                                                                                      \
-  "v_mad_u32_u16 v48, %11, 1, %15\n\t"                                                                        \
+// Tap loop of the quad shape: 4 x 8-byte reads per tap, rows i = 0..3 land in v[base+2i : base+2i+1] = the operands of
+// accumulators 2i (columns j, j+32) and 2i+1 (columns j+64, j+96); the LDS address is one v_mad_u32_u16 (low 16 bits of
+// the ltap word + lane base).  Same arithmetic and the same one-tap LDS look-ahead as tap_loop_narrow; the scalar side
+// is leaner because every instruction a wave issues costs launch time here (measured by padding the loop: +0.24 us per
+// million scalar, +0.69 per million vector, +1.25 per million LDS instructions): the ltap words
+// arrive two at a time (s_load_dwordx2) into three fixed register pairs P = s[36:37], Q = s[38:39], R = s[40:41] that the
+// 6-way unrolled body addresses by name, so nothing is moved between "current / next / in flight" registers: per tap
+// 1 wait + 1/2 load + 1/2 add + 1 subtract + 1 branch instead of 7 scalar instructions.  A pair is reloaded in the tap
+// after its last use and first used three taps later (with two pairs and one tap of cover the waits ran into the
+// scalar loads: no faster than the old loop).
+//   tap 6k  : load R <- w[6k+4..5] | read Y at offset(P.hi) | multiply-add X by weight(P.lo)
+//   tap 6k+1:                        read X at offset(Q.lo) | multiply-add Y by weight(P.hi)
+//   tap 6k+2: load P <- w[6k+6..7] | read Y at offset(Q.hi) | multiply-add X by weight(Q.lo)
+//   tap 6k+3:                        read X at offset(R.lo) | multiply-add Y by weight(Q.hi)
+//   tap 6k+4: load Q <- w[6k+8..9] | read Y at offset(R.hi) | multiply-add X by weight(R.lo)
+//   tap 6k+5:                        read X at offset(P.lo) | multiply-add Y by weight(R.hi)
+// Operands: %0-%7 accumulators, %8 byte offset of the next ltap pair, %9 taps left, %10 ltaps, %11 lane base.
+#define DIBQ_MUL(b, W) "v_pk_mul_f16 v" #b ", " W ", v" #b " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+#define DIBQ_FMA(b, i, W) "v_pk_fma_f16 %" #i ", " W ", v" #b ", %" #i " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define DIBQ_MADD_X(W) DIBQ_MUL(32, W) DIBQ_MUL(33, W) DIBQ_MUL(34, W) DIBQ_MUL(35, W) DIBQ_MUL(36, W) DIBQ_MUL(37, W) DIBQ_MUL(38, W) DIBQ_MUL(39, W) \
+  DIBN_ADD(32, 0) DIBN_ADD(33, 1) DIBN_ADD(34, 2) DIBN_ADD(35, 3) DIBN_ADD(36, 4) DIBN_ADD(37, 5) DIBN_ADD(38, 6) DIBN_ADD(39, 7)
+#define DIBQ_MADD_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(41, W) DIBQ_MUL(42, W) DIBQ_MUL(43, W) DIBQ_MUL(44, W) DIBQ_MUL(45, W) DIBQ_MUL(46, W) DIBQ_MUL(47, W) \
+  DIBN_ADD(40, 0) DIBN_ADD(41, 1) DIBN_ADD(42, 2) DIBN_ADD(43, 3) DIBN_ADD(44, 4) DIBN_ADD(45, 5) DIBN_ADD(46, 6) DIBN_ADD(47, 7)
+#define DIBQ_FMADD_X(W) DIBQ_FMA(32, 0, W) DIBQ_FMA(33, 1, W) DIBQ_FMA(34, 2, W) DIBQ_FMA(35, 3, W) DIBQ_FMA(36, 4, W) DIBQ_FMA(37, 5, W) DIBQ_FMA(38, 6, W) DIBQ_FMA(39, 7, W)
+#define DIBQ_FMADD_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(41, 1, W) DIBQ_FMA(42, 2, W) DIBQ_FMA(43, 3, W) DIBQ_FMA(44, 4, W) DIBQ_FMA(45, 5, W) DIBQ_FMA(46, 6, W) DIBQ_FMA(47, 7, W)
+#define DIBQ_READ(base, OFF)                                                                                 \
+  "v_mad_u32_u16 v48, " OFF ", 1, %11\n\t"                                                                    \
   "ds_read_b64 v[" #base ":" #base "+1], v48\n\tds_read_b64 v[" #base "+2:" #base "+3], v48 offset:448\n\t"    \
   "ds_read_b64 v[" #base "+4:" #base "+5], v48 offset:896\n\tds_read_b64 v[" #base "+6:" #base "+7], v48 offset:1344\n\t"
-#ifdef DIBQ_SENS   // scratch: sensitivity of the launch time to 4 more instructions of one kind per tap (never in the product build)
-#if DIBQ_SENS == 1
-#define DIBQ_PAD(b) "s_mov_b32 %13, %13\n\ts_mov_b32 %13, %13\n\ts_mov_b32 %13, %13\n\ts_mov_b32 %13, %13\n\t"
-#elif DIBQ_SENS == 2
-#define DIBQ_PAD(b) "v_mov_b32 v48, v48\n\tv_mov_b32 v48, v48\n\tv_mov_b32 v48, v48\n\tv_mov_b32 v48, v48\n\t"
-#elif DIBQ_SENS == 3
-#define DIBQ_PAD(b) "ds_read_b64 v[" #b ":" #b "+1], v48\n\tds_read_b64 v[" #b ":" #b "+1], v48\n\tds_read_b64 v[" #b ":" #b "+1], v48\n\tds_read_b64 v[" #b ":" #b "+1], v48\n\t"
-#else
-#define DIBQ_PAD(b)
-#endif
-#else
-#define DIBQ_PAD(b)
-#endif
+#define DIBQ_LOAD(PAIR) "s_load_dwordx2 " PAIR ", %10, %8\n\ts_add_u32 %8, %8, 8\n\t"
+#define DIBQ_NEXT(LABEL) "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 " LABEL "\n\t"
 template <bool FUSED>
 __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
-  unsigned sA, sB, sC, st;
   unsigned a[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
-#define DIB_RQ_ASM(ARITH_A, ARITH_B) \
+#define DIB_RQ_ASM(ARITH_X, ARITH_Y) \
   asm volatile( \
-      "s_load_dword %11, %14, %8\n\ts_add_u32 %8, %8, 4\n\t" DIBN_NEXTTAP \
-      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIBQ_READ(32) \
+      DIBQ_LOAD("s[36:37]") DIBQ_LOAD("s[38:39]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIBQ_READ(32, "s36") \
       "Ldibq_loop%=:\n\t" \
-      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
-      DIBQ_READ(40) DIBQ_PAD(40) DIBN_NEXTTAP \
-      ARITH_A \
-      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 Ldibq_done%=\n\t" \
-      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
-      DIBQ_READ(32) DIBQ_PAD(32) DIBN_NEXTTAP \
-      ARITH_B \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[40:41]") DIBQ_READ(40, "s37") ARITH_X("s36") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_READ(32, "s38") ARITH_Y("s37") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[36:37]") DIBQ_READ(40, "s39") ARITH_X("s38") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_READ(32, "s40") ARITH_Y("s39") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[38:39]") DIBQ_READ(40, "s41") ARITH_X("s40") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_READ(32, "s36") ARITH_Y("s41") \
       "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc0 Ldibq_loop%=\n\t" \
       "Ldibq_done%=:\n\t" \
       "s_waitcnt lgkmcnt(0)" \
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+s"(toff), "+s"(cnt), \
-        "=&s"(sA), "=&s"(sB), "=&s"(sC), "=&s"(st) \
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+s"(toff), "+s"(cnt) \
       : "s"(ltaps), "v"(lane_addr) \
-      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "scc", \
-        "memory")
-  if constexpr (FUSED) { DIB_RQ_ASM(DIBN_FMADD_A, DIBN_FMADD_B); } else { DIB_RQ_ASM(DIBN_MADD_A, DIBN_MADD_B); }
+      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", \
+        "s36", "s37", "s38", "s39", "s40", "s41", "scc", "memory")
+  if constexpr (FUSED) { DIB_RQ_ASM(DIBQ_FMADD_X, DIBQ_FMADD_Y); } else { DIB_RQ_ASM(DIBQ_MADD_X, DIBQ_MADD_Y); }
 #undef DIB_RQ_ASM
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
@@ -718,8 +725,18 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   const int H = d.H, W = d.W, w2 = W * 2;
   const int mode = pad_mode_for(K, H, W);
   const int pb = K / 2 - 1, pa = K / 2;
-  const int nsegs = tab[HDR_NSEGS];
+  // second (and last) scalar round trip of the prologue: segment count and first segment, requested together.  Written
+  // out because hipcc turns these into vector loads + v_readfirstlane once an asm statement precedes them.
   const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
+  int nsegs;
+  uint4 seg;
+  {
+    unsigned __int128 r;
+    asm volatile("s_load_dword %0, %2, 0x1c\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(nsegs), "=&s"(r) : "s"((unsigned long long)tab), "s"((unsigned long long)segs));
+    seg = make_uint4((unsigned)r, (unsigned)(r >> 32), (unsigned)(r >> 64), (unsigned)(r >> 96));
+  }
+  static_assert(HDR_NSEGS * 4 == 0x1c, "offset of the segment count in the asm above");
   const unsigned long long la = (unsigned long long)(tab + table_ltaps_q_off(K));
   const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
                                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
@@ -738,7 +755,8 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   typedef __attribute__((address_space(3))) lds_u2v lds_u2;
 
   for (int sg = 0; sg < nsegs; ++sg) {
-    const Window w = window_of(segs[sg]);
+    if (sg > 0) seg = segs[sg];
+    const Window w = window_of(seg);
     const int lane = fresh_lane();
     // ---- fill: per LDS row the four values P[lane + 32 m] of element `lane` ----------------------------------------
     short v[GQ][4];
@@ -779,15 +797,6 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
     }
-#if defined(DIBQ_SENS) && DIBQ_SENS == 4   // +11 window loads per fill
-    {
-      short dummy[GQ];
-#pragma unroll
-      for (int g = 0; g < GQ; ++g) dummy[g] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[0] + 2u, __builtin_amdgcn_readfirstlane(soff[g]), 0);
-#pragma unroll
-      for (int g = 0; g < GQ; ++g) asm volatile("" :: "v"(dummy[g]));
-    }
-#endif
     if (sg > 0) __syncthreads();  // every wave is done reading the previous window
     // Elements 0 .. 31 + column extent are read by the taps; writing all 56 of a row costs the same (an LDS store is
     // priced per instruction), lanes 56-63 own no element.  The two 16-bit values of a word are merged by v_perm_b32
@@ -840,10 +849,6 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       __builtin_amdgcn_raw_buffer_store_b16((short)(a0 >> 16), out_rsrc, row_ok && xl + 32 < W ? ro + 64u : oob, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b16((short)(a1 & 0xffffu), out_rsrc, row_ok && xl + 64 < W ? ro + 128u : oob, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b16((short)(a1 >> 16), out_rsrc, row_ok && xl + 96 < W ? ro + 192u : oob, 0, 0);
-#if defined(DIBQ_SENS) && DIBQ_SENS == 5   // +8 stores per wave (the same bytes again)
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a0 & 0xffffu), out_rsrc, row_ok && xl < W ? ro : oob, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a1 & 0xffffu), out_rsrc, row_ok && xl + 64 < W ? ro + 128u : oob, 0, 0);
-#endif
     }
   }
 }
@@ -868,13 +873,17 @@ __global__ __launch_bounds__(256, 8) void blur_narrow_f16_kernel(BlurBatch batch
     nlds[TL_WORD + 2] = blockIdx.y * 1024 + blockIdx.x;   // x extent of the BASELINE launch: 832
   }
 #endif
-  const ImageDesc &d = batch.img[blockIdx.y];
+  // Prologue = two scalar round trips.  First: the whole descriptor, K and the table base, requested together (left to
+  // hipcc the fields are fetched one use at a time, a wait in front of each: six dependent round trips per workgroup).
+  const ImageDesc d = batch.img[blockIdx.y];
+  asm volatile("" ::"s"(d.in), "s"(d.out), "s"(d.C), "s"(d.H), "s"(d.W), "s"(d.table), "s"(d.tiles_x), "s"(d.tiles_y),
+               "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(tables), "s"(K));
   const int per_ch = d.tiles_x * d.tiles_y;
   int local;
   if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
-  const int ch = local / per_ch;
+  const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
-  const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
+  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
   if constexpr (QUAD) blur_quad_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, nlds);
   else blur_narrow_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, nlds);
 #ifdef DIB_TIMELINE
@@ -904,9 +913,9 @@ __global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch b
     local = blockIdx.x;              // flat order (the traffic experiment): tile index = block index
     if (local >= d.C * per_ch) return;
   }
-  const int ch = local / per_ch;
+  const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
-  const int ty = local / d.tiles_x, tx = local - ty * d.tiles_x;
+  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
   blur_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, lds, dbg);
 }
 
@@ -1041,6 +1050,13 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       return DIB_EINVAL;
     }
     if (in_dev[i] == out_dev[i]) { set_error("dib_sparse_blur: image %d: out aliases in", i); return DIB_EINVAL; }
+    {   // the tile index split (magic_div) is exact while channels x tiles-per-channel^2 < 2^32: ~150 Mpixel per channel
+      const unsigned long long per_ch = (unsigned long long)((W[i] + 127) / 128) * ((H[i] + 31) / 32);
+      if ((unsigned long long)C[i] * per_ch * per_ch >= 0x100000000ull) {
+        set_error("dib_sparse_blur: image %d (%d x %d x %d) is too large", i, C[i], H[i], W[i]);
+        return DIB_ESHAPE;
+      }
+    }
     // F.pad(mode='reflect') raises unless pad < dim (blur_functions.py:59 with pads 63/64)
     if (K == 128 && !(H[i] < 64 || W[i] < 64) && (H[i] == 64 || W[i] == 64)) {
       set_error("Padding size should be less than the corresponding input dimension (image %d is %dx%d)", i, H[i], W[i]);
@@ -1065,6 +1081,8 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       d.in = in_dev[i]; d.out = out_dev[i]; d.C = C[i]; d.H = H[i]; d.W = W[i]; d.table = table_index[i];
       d.tiles_x = narrow ? (W[i] + NTILE_W - 1) / NTILE_W : (W[i] + TILE_W - 1) / TILE_W;
       d.tiles_y = (H[i] + TH - 1) / TH;
+      d.inv_per_ch = magic_inverse((unsigned)(d.tiles_x * d.tiles_y));
+      d.inv_tiles_x = magic_inverse((unsigned)d.tiles_x);
       d.tile_begin = tiles;
       tiled.tile_begin[tiled.n] = tiles;
       tiles += d.C * d.tiles_x * d.tiles_y;

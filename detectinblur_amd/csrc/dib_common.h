@@ -79,7 +79,14 @@ struct ImageDesc {
   int tile_begin;  // first flattened tile id of this image in the launch
   int tiles_x;     // tiles per row (128 or 256 px wide, by the shape of the launch)
   int tiles_y;     // 32-row tiles per channel
+  // floor(2^32 / d) + 1 for d = tiles_x * tiles_y and d = tiles_x (0 when d == 1): the workgroup's tile index is split into
+  // (channel, tile row, tile column) with two multiplies instead of two ~25-instruction scalar divisions per wave
+  unsigned inv_per_ch, inv_tiles_x;
 };
+
+// n / d for n * d < 2^32, inv = floor(2^32 / d) + 1 (exact: the error term n * (inv * d - 2^32) / (d * 2^32) stays below 1 / d)
+__host__ __device__ inline unsigned magic_inverse(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / d) + 1u; }
+__device__ __forceinline__ int magic_div(int n, unsigned inv) { return inv ? (int)__umulhi((unsigned)n, inv) : n; }
 
 struct BlurBatch {
   ImageDesc img[MAX_BATCH];
