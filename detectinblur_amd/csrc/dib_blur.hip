@@ -676,24 +676,35 @@ static_assert(LROWS % NW == 0, "every wave fills the same number of window rows"
   "v_mad_u32_u16 v48, " OFF ", 1, %11\n\t"                                                                    \
   "ds_read_b64 v[" #base ":" #base "+1], v48\n\tds_read_b64 v[" #base "+2:" #base "+3], v48 offset:448\n\t"    \
   "ds_read_b64 v[" #base "+4:" #base "+5], v48 offset:896\n\tds_read_b64 v[" #base "+6:" #base "+7], v48 offset:1344\n\t"
+// HALF variant: a tile with at most 64 valid columns (the right-hand edge of an image whose width is not a multiple of
+// 128: 1333 = 10 x 128 + 53) only needs the first word {P[k], P[k+32]} of every element: 4-byte reads, 4 + 4 instead of
+// 8 + 8 arithmetic instructions per tap, on the even registers / accumulators.
+#define DIBQ_READH(base, OFF)                                                                                \
+  "v_mad_u32_u16 v48, " OFF ", 1, %11\n\t"                                                                    \
+  "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+2], v48 offset:448\n\t"                            \
+  "ds_read_b32 v[" #base "+4], v48 offset:896\n\tds_read_b32 v[" #base "+6], v48 offset:1344\n\t"
+#define DIBQ_MADDH_X(W) DIBQ_MUL(32, W) DIBQ_MUL(34, W) DIBQ_MUL(36, W) DIBQ_MUL(38, W) DIBN_ADD(32, 0) DIBN_ADD(34, 2) DIBN_ADD(36, 4) DIBN_ADD(38, 6)
+#define DIBQ_MADDH_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(42, W) DIBQ_MUL(44, W) DIBQ_MUL(46, W) DIBN_ADD(40, 0) DIBN_ADD(42, 2) DIBN_ADD(44, 4) DIBN_ADD(46, 6)
+#define DIBQ_FMADDH_X(W) DIBQ_FMA(32, 0, W) DIBQ_FMA(34, 2, W) DIBQ_FMA(36, 4, W) DIBQ_FMA(38, 6, W)
+#define DIBQ_FMADDH_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(42, 2, W) DIBQ_FMA(44, 4, W) DIBQ_FMA(46, 6, W)
 #define DIBQ_LOAD(PAIR) "s_load_dwordx2 " PAIR ", %10, %8\n\ts_add_u32 %8, %8, 8\n\t"
 #define DIBQ_NEXT(LABEL) "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 " LABEL "\n\t"
-template <bool FUSED>
+template <bool FUSED, bool HALF>
 __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
   unsigned a[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
-#define DIB_RQ_ASM(ARITH_X, ARITH_Y) \
+#define DIB_RQ_ASM(RD, ARITH_X, ARITH_Y) \
   asm volatile( \
-      DIBQ_LOAD("s[36:37]") DIBQ_LOAD("s[38:39]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIBQ_READ(32, "s36") \
+      DIBQ_LOAD("s[36:37]") DIBQ_LOAD("s[38:39]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(32, "s36") \
       "Ldibq_loop%=:\n\t" \
-      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[40:41]") DIBQ_READ(40, "s37") ARITH_X("s36") DIBQ_NEXT("Ldibq_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_READ(32, "s38") ARITH_Y("s37") DIBQ_NEXT("Ldibq_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[36:37]") DIBQ_READ(40, "s39") ARITH_X("s38") DIBQ_NEXT("Ldibq_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_READ(32, "s40") ARITH_Y("s39") DIBQ_NEXT("Ldibq_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[38:39]") DIBQ_READ(40, "s41") ARITH_X("s40") DIBQ_NEXT("Ldibq_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_READ(32, "s36") ARITH_Y("s41") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[40:41]") RD(40, "s37") ARITH_X("s36") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s38") ARITH_Y("s37") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[36:37]") RD(40, "s39") ARITH_X("s38") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s40") ARITH_Y("s39") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[38:39]") RD(40, "s41") ARITH_X("s40") DIBQ_NEXT("Ldibq_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s36") ARITH_Y("s41") \
       "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc0 Ldibq_loop%=\n\t" \
       "Ldibq_done%=:\n\t" \
       "s_waitcnt lgkmcnt(0)" \
@@ -701,7 +712,10 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
       : "s"(ltaps), "v"(lane_addr) \
       : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", \
         "s36", "s37", "s38", "s39", "s40", "s41", "scc", "memory")
-  if constexpr (FUSED) { DIB_RQ_ASM(DIBQ_FMADD_X, DIBQ_FMADD_Y); } else { DIB_RQ_ASM(DIBQ_MADD_X, DIBQ_MADD_Y); }
+  if constexpr (FUSED && HALF) { DIB_RQ_ASM(DIBQ_READH, DIBQ_FMADDH_X, DIBQ_FMADDH_Y); }
+  else if constexpr (FUSED) { DIB_RQ_ASM(DIBQ_READ, DIBQ_FMADD_X, DIBQ_FMADD_Y); }
+  else if constexpr (HALF) { DIB_RQ_ASM(DIBQ_READH, DIBQ_MADDH_X, DIBQ_MADDH_Y); }
+  else { DIB_RQ_ASM(DIBQ_READ, DIBQ_MADD_X, DIBQ_MADD_Y); }
 #undef DIB_RQ_ASM
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
@@ -831,7 +845,8 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     __syncthreads();
     const int tl = fresh_lane();
     const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
-    tap_loop_quad<ACC == DIB_ACC_FMA16>(acc, ltaps, w.t0, w.n, lane_addr);
+    if (W - x0 <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true>(acc, ltaps, w.t0, w.n, lane_addr);
+    else tap_loop_quad<ACC == DIB_ACC_FMA16, false>(acc, ltaps, w.t0, w.n, lane_addr);
   }
   // ---- store: a store instruction writes 32 columns of row y (lanes 0-31) and of row y + 4 (lanes 32-63); lanes
   // outside the image get an out-of-range buffer offset and are dropped by the range check ----------------------------
