@@ -855,6 +855,26 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     const int sl = fresh_lane();
     const int yl = y0 + wave * 8 + (sl >> 5) * 4, xl = x0 + (sl & 31);
     const unsigned base = (unsigned)(yl * w2 + xl * 2), oob = 0x7ffffff0u;
+    if (x0 + QTILE_W <= W && y0 + TH <= H) {
+      // tile inside the image (5 of 6 at 800 x 1333): one address register, the row in the scalar offset, the column
+      // block in the immediate offset, the high halves stored straight from the registers -- no vector instruction at all
+      // (the general form below costs ~45 per wave).  Written out: there is no builtin for the d16_hi stores.
+      typedef int i4v __attribute__((ext_vector_type(4)));
+      const unsigned long long pa2 = (unsigned long long)d.out + (unsigned long long)ch * H * W * 2ull;   // as plane_rsrc
+      const i4v rs = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa2), __builtin_amdgcn_readfirstlane((int)(unsigned)(pa2 >> 32)) & 0xffff,
+                      H * W * 2, 0x00020000};
+      int so = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        asm volatile("buffer_store_short %0, %2, %3, %4 offen\n\t"
+                     "buffer_store_short_d16_hi %0, %2, %3, %4 offen offset:64\n\t"
+                     "buffer_store_short %1, %2, %3, %4 offen offset:128\n\t"
+                     "buffer_store_short_d16_hi %1, %2, %3, %4 offen offset:192"
+                     :: "v"(acc[2 * i]), "v"(acc[2 * i + 1]), "v"(base), "s"(rs), "s"(so) : "memory");
+        so += w2;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool row_ok = yl + i < H;
