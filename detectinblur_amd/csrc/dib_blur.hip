@@ -899,8 +899,12 @@ constexpr int TL_WORD = (QLDS_BYTES > NLDS_BYTES ? QLDS_BYTES : NLDS_BYTES) / 4;
 #else
 #endif
 
-template <int ACC, bool QUAD>
-__global__ __launch_bounds__(256, 8) void blur_narrow_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K) {
+// KC: the PSF canvas (128 or 256) as a compile-time constant -- table offsets, pads and the padding mode fold, ~50 scalar
+// instructions of every workgroup's prologue.  An instruction on a workgroup's serial path costs launch time out of
+// proportion (8 waves per SIMD: ~10 cycles per instruction and wave, times 3.2 rounds of workgroups).
+template <int ACC, bool QUAD, int KC>
+__global__ __launch_bounds__(256, 8) void blur_narrow_f16_kernel(BlurBatch batch) {
+  constexpr int K = KC;
   extern __shared__ unsigned nlds[];
 #ifdef DIB_TIMELINE
   if (threadIdx.x == 0) {   // 16 more bytes of LDS
@@ -912,15 +916,15 @@ __global__ __launch_bounds__(256, 8) void blur_narrow_f16_kernel(BlurBatch batch
   // hipcc the fields are fetched one use at a time, a wait in front of each: six dependent round trips per workgroup).
   const ImageDesc d = batch.img[blockIdx.y];
   asm volatile("" ::"s"(d.in), "s"(d.out), "s"(d.C), "s"(d.H), "s"(d.W), "s"(d.table), "s"(d.tiles_x), "s"(d.tiles_y),
-               "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(tables), "s"(K));
+               "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab));
   const int per_ch = d.tiles_x * d.tiles_y;
   int local;
   if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
   const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  if constexpr (QUAD) blur_quad_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, nlds);
-  else blur_narrow_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, nlds);
+  if constexpr (QUAD) blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds);
+  else blur_narrow_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds);
 #ifdef DIB_TIMELINE
   if (threadIdx.x == 0) {
     unsigned long long *tl = DIB_TL_SLOT;
@@ -1057,10 +1061,14 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_BITEXACT>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FP32>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FMA16>, LDS_BYTES));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false>), NLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, false>), NLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true>), QLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, true>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false, 128>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, false, 128>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true, 128>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, true, 128>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false, 256>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, false, 256>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true, 256>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, true, 256>), QLDS_BYTES + TL_EXTRA));
     st.ready = true;
   }
   return DIB_OK;
@@ -1118,6 +1126,7 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       d.tiles_y = (H[i] + TH - 1) / TH;
       d.inv_per_ch = magic_inverse((unsigned)(d.tiles_x * d.tiles_y));
       d.inv_tiles_x = magic_inverse((unsigned)d.tiles_x);
+      d.tab = (const int *)tables_dev + (size_t)table_index[i] * table_words(K);
       d.tile_begin = tiles;
       tiled.tile_begin[tiled.n] = tiles;
       tiles += d.C * d.tiles_x * d.tiles_y;
@@ -1150,10 +1159,16 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
         gx = ext > gx ? ext : gx;
       }
       const dim3 grid(gx, tiled.n);
-      if (quad && acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_FMA16, true>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, (const int *)tables_dev, K);
-      else if (quad) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, (const int *)tables_dev, K);
-      else if (narrow && acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_FMA16, false>), grid, dim3(256), NLDS_BYTES + TL_EXTRA, s, tiled, (const int *)tables_dev, K);
-      else if (narrow) hipLaunchKernelGGL((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false>), grid, dim3(256), NLDS_BYTES + TL_EXTRA, s, tiled, (const int *)tables_dev, K);
+#define DIB_LAUNCH_128(ACCM, Q, LDSB)                                                                                       \
+  do {                                                                                                                     \
+    if (K == 128) hipLaunchKernelGGL((blur_narrow_f16_kernel<ACCM, Q, 128>), grid, dim3(256), (LDSB) + TL_EXTRA, s, tiled); \
+    else hipLaunchKernelGGL((blur_narrow_f16_kernel<ACCM, Q, 256>), grid, dim3(256), (LDSB) + TL_EXTRA, s, tiled);          \
+  } while (0)
+      if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_128(DIB_ACC_FMA16, true, QLDS_BYTES);
+      else if (quad) DIB_LAUNCH_128(DIB_ACC_BITEXACT, true, QLDS_BYTES);
+      else if (narrow && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_128(DIB_ACC_FMA16, false, NLDS_BYTES);
+      else if (narrow) DIB_LAUNCH_128(DIB_ACC_BITEXACT, false, NLDS_BYTES);
+#undef DIB_LAUNCH_128
       else if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FP32>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FMA16>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
@@ -1173,7 +1188,7 @@ extern "C" int dib_sparse_blur_generic(const void *in_dev, void *out_dev, int C,
   BlurBatch g;
   g.n = 1;
   ImageDesc d;
-  d.in = in_dev; d.out = out_dev; d.C = C; d.H = H; d.W = W; d.table = 0; d.tile_begin = 0; d.tiles_x = d.tiles_y = 0;
+  d.in = in_dev; d.out = out_dev; d.C = C; d.H = H; d.W = W; d.table = 0; d.tile_begin = 0; d.tiles_x = d.tiles_y = 0; d.inv_per_ch = d.inv_tiles_x = 0; d.tab = (const int *)table_dev;
   g.img[0] = d;
   int blocks = (int)(((long long)C * H * W + 255) / 256);
   g.total_tiles = blocks;

@@ -82,6 +82,7 @@ struct ImageDesc {
   // floor(2^32 / d) + 1 for d = tiles_x * tiles_y and d = tiles_x (0 when d == 1): the workgroup's tile index is split into
   // (channel, tile row, tile column) with two multiplies instead of two ~25-instruction scalar divisions per wave
   unsigned inv_per_ch, inv_tiles_x;
+  const int *tab;  // this image's tap table (tables + table * table_words(K)), formed on the host
 };
 
 // n / d for n * d < 2^32, inv = floor(2^32 / d) + 1 (exact: the error term n * (inv * d - 2^32) / (d * 2^32) stays below 1 / d)
