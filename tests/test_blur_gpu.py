@@ -478,3 +478,48 @@ def test_psf_sum_equals_torch_half_sum_on_generated_psfs():
         got.append((hdr & 0xffff).to(torch.int32))
     got = torch.cat(got)
     assert torch.equal(got, want.to(torch.int32) & 0xffff)
+
+
+def test_compaction_and_blur_are_graph_capturable():
+    """The boundary takes a stream and never synchronises, copies or allocates behind the caller's back: tap compaction +
+    blur captured into a HIP graph (two steps on two captured streams, as bench.py runs them) replay to the bit-identical
+    result of the eager calls, for fresh input written between replays."""
+    from detectinblur_amd import blur_ops
+    rs = np.random.RandomState(5)
+    imgs = [_dev(rs.random_sample((3, 97, 301)).astype(np.float16)), _dev(rs.random_sample((1, 200, 140)).astype(np.float16))]
+    psfs = []
+    for n in (12, 40):
+        a = np.zeros((128, 128), np.float16)
+        a[rs.randint(50, 80, n), rs.randint(50, 80, n)] = (rs.random_sample(n) + 0.1).astype(np.float16)
+        psfs.append(_dev(a))
+
+    def step():
+        tables = blur_ops.compact_psfs(psfs, normalize=True)
+        return blur_ops.sparse_blur(list(imgs), [0, 1], tables), tables
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    g = torch.cuda.CUDAGraph()
+    keep = []
+    with torch.cuda.graph(g, stream=streams[0], capture_error_mode="thread_local"):
+        fork = torch.cuda.Event()
+        fork.record(streams[0])
+        streams[1].wait_event(fork)
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                keep.append(step())
+        join = torch.cuda.Event()
+        join.record(streams[1])
+        streams[0].wait_event(join)
+    for trial in range(2):
+        for t in imgs:                                  # new pixels in the same buffers
+            t.copy_(torch.rand(t.shape, device=t.device).half())
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        want, _ = step()
+        for outs, _ in keep:
+            for a, b in zip(outs, want):
+                assert torch.equal(a, b)
