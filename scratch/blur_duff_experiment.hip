@@ -1,0 +1,1225 @@
+// Sparse PSF (x) image correlation for gfx950 (CDNA4) -- the `--gpu_blur` hot loop.
+//
+// Reference: models/blur_functions.py:11-69 (`manual_blur`): pad, then for EVERY non-zero tap a
+// full-image torch.roll + mul + add_ (about 10 launches, 2 host syncs and 73 MB of HBM traffic per
+// tap).  Here: one launch per batch, every source pixel fetched from HBM once (plus halo re-reads
+// served by L2), the padded image never materialised (index math), taps broadcast from SGPRs.
+//
+// Arithmetic contract (DIB_ACC_BITEXACT): per output element, taps in row-major order,
+//     acc = rnd16(acc + rnd16(P * w))            (v_pk_mul_f16 + v_pk_add_f16, never an FMA)
+// which is bit-identical to the reference's Half tensors.
+//
+// Tiled fp16 kernel -- memory layout in LDS ("split-column" layout):
+//   A workgroup owns a 256 x 32 output tile of ONE channel.  Lane l of every wave owns the four
+//   columns x0 + l + 64k (k = 0..3), packed as two fp16x2 registers per row.  LDS row q holds the
+//   source window row as 8-byte words:  word j = { P[j], P[j+64], P[j+128], P[j+192] },
+//   j in [0, 64+ex), where P is the (virtually padded) source row starting at column
+//   x0 + pb - cmax and ex = cmax - cmin is the column extent of the tap SEGMENT being processed.
+//   A tap (r, c) is then ONE aligned, bank-conflict-free ds_read_b64 at word  lane + (cmax - c)
+//   for ANY column shift -- odd shifts included.  (Measured on MI355X: a ds_read_b64 that is not
+//   8-byte aligned runs 22x slower, so a plain row-major fp16 window is not an option.)
+//   Row shifts are LDS row offsets; the R rows a lane owns use compile-time immediate offsets.
+//   The tap list arrives cut into segments (dib_compact.hip) whose bounding box is at most
+//   17 PSF rows x 33 PSF columns, so ONE small LDS window (48 rows x 96 words = 36 KB, four
+//   workgroups per CU) serves any PSF; a wide or tall PSF simply takes several fill+accumulate
+//   rounds, in tap order, with the accumulators staying in registers.
+//
+// What bounds it (measured, scratch/ubench): a packed fp16 instruction occupies a SIMD for 4 cycles
+// per wave (1.9 ns at the clock the chip holds; 3.2 ns with one wave alone), the same per-element rate as
+// fp32 (MI355X_MICROARCH.md: SIMD-32, v_fma_f32 2 cycles per wave).  The bit-exact contract needs a
+// multiply AND an add per 2 pixel-taps: 15.1 M wave-instructions for the BASELINE batch = ~26 us of
+// pure VALU time on 1024 SIMDs, above its 16 us HBM time.  Everything else -- window fills, stores,
+// launch ramp -- has to hide behind that arithmetic, i.e. behind the other three workgroups of the CU.
+#include "dib_common.h"
+#include <hip/hip_fp16.h>
+#include <mutex>
+#include <stdlib.h>
+
+namespace dib {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+constexpr int TILE_W = 256;
+constexpr int PQ = WIN_PITCH;         // LDS row pitch in 8-byte words (96)
+constexpr int TH = 32;                // tile rows
+constexpr int LROWS = TH + SEG_ROWS;  // LDS rows per window (48)
+constexpr int LDS_BYTES = LROWS * PQ * 8;  // 36,864 B: four workgroups per CU
+static_assert(WIN_PITCH * 8 == 768, "the asm below hard-codes the LDS row pitch");
+
+// 64-bit asm operands must be scalar integers: hipcc (ROCm 7.2) aliases both lanes of a
+// 2 x 32-bit vector operand of an inline-asm "=v" output to the same register.
+typedef unsigned long long u2;
+
+// ---- the tap loop, hand-written ------------------------------------------------------------------
+// Left to hipcc the loop serialises (it merges the 8-byte LDS reads into half-rate ds_read2_b64,
+// sinks the scalar tap load to its first use and waits right behind every access), and stitching
+// it from several asm statements costs ~20 scalar instructions per tap in glue (asm results count
+// as divergent, so loop-carried scalars bounce through VGPRs).  The whole loop of one tap segment
+// is therefore ONE asm statement with fixed buffer registers:
+//     v[64:79]  buffer A: the 8 rows x 8 bytes of the current tap, multiplied in place
+//     v[80:95]  buffer B: same for the following tap (the two alternate)
+//     v96       LDS address
+//   per tap:  s_waitcnt lgkmcnt(0)          data of this tap + ltap word of the next one arrived
+//             8 x ds_read_b64 -> other buf  next tap's data (address = its ltap offset + lane base)
+//             s_load_dword                  ltap word of the tap after next
+//             16 x v_pk_mul_f16, 16 x v_pk_add_f16 on this tap's data while all of that is in flight
+// 7 scalar + 1 vector instruction of overhead per 32 packed operations.  Scalar instructions matter
+// here: with one or two waves per SIMD in their tap loops a wave's own SALU work is on its critical
+// path, it is not hidden behind another wave's VALU.  Hence: the weight is read straight from the high
+// half of the ltap SGPR (op_sel, no shift + pack), the LDS address is one v_mad_u32_u16 (no scalar mask),
+// the loop ends on the borrow of the counter's decrement, and the last tap does not branch around its
+// (harmless, zero-padded) look-ahead.
+// (Also built and measured: a x3-unrolled loop with THREE data buffers -- LDS look-ahead of two taps,
+// `s_waitcnt lgkmcnt(8)` -- that takes its ltap words from a VGPR with v_readlane.  Bit-identical, 3 % slower:
+// LDS latency is already covered by one tap of look-ahead.)
+// ltap word = byte offset of the tap's source word in the window (low 16) | fp16 weight (high 16).
+// Operands: %0-%15 accumulators, %16 byte offset of the next ltap, %17 taps left, %18 A (tap being
+// multiplied), %19 B (tap being fetched), %20 C (tap in flight), %21 scalar temp, %22 ltaps, %23 lane base.
+//
+// HALF variant: a tile whose valid columns all lie in its first 128 (the right-hand edge column of an
+// image whose width is not a multiple of 256: 1333 = 5 x 256 + 53) only has the packed registers
+// {P[j], P[j+64]}: 4-byte LDS reads, 8 multiplies + 8 adds per tap instead of 16 + 16.
+#define DIB_MUL(b) "v_pk_mul_f16 v" #b ", %18, v" #b " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+#define DIB_ADD(b, i) "v_pk_add_f16 %" #i ", %" #i ", v" #b "\n\t"
+#define DIB_FMA(b, i) "v_pk_fma_f16 %" #i ", %18, v" #b ", %" #i " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define DIB_MADD_A                                                                                          \
+  DIB_MUL(64) DIB_MUL(65) DIB_MUL(66) DIB_MUL(67) DIB_MUL(68) DIB_MUL(69) DIB_MUL(70) DIB_MUL(71) \
+  DIB_MUL(72) DIB_MUL(73) DIB_MUL(74) DIB_MUL(75) DIB_MUL(76) DIB_MUL(77) DIB_MUL(78) DIB_MUL(79) \
+  DIB_ADD(64, 0) DIB_ADD(65, 1) DIB_ADD(66, 2) DIB_ADD(67, 3) DIB_ADD(68, 4) DIB_ADD(69, 5) DIB_ADD(70, 6) DIB_ADD(71, 7) \
+  DIB_ADD(72, 8) DIB_ADD(73, 9) DIB_ADD(74, 10) DIB_ADD(75, 11) DIB_ADD(76, 12) DIB_ADD(77, 13) DIB_ADD(78, 14) DIB_ADD(79, 15)
+#define DIB_MADD_B                                                                                          \
+  DIB_MUL(80) DIB_MUL(81) DIB_MUL(82) DIB_MUL(83) DIB_MUL(84) DIB_MUL(85) DIB_MUL(86) DIB_MUL(87) \
+  DIB_MUL(88) DIB_MUL(89) DIB_MUL(90) DIB_MUL(91) DIB_MUL(92) DIB_MUL(93) DIB_MUL(94) DIB_MUL(95) \
+  DIB_ADD(80, 0) DIB_ADD(81, 1) DIB_ADD(82, 2) DIB_ADD(83, 3) DIB_ADD(84, 4) DIB_ADD(85, 5) DIB_ADD(86, 6) DIB_ADD(87, 7) \
+  DIB_ADD(88, 8) DIB_ADD(89, 9) DIB_ADD(90, 10) DIB_ADD(91, 11) DIB_ADD(92, 12) DIB_ADD(93, 13) DIB_ADD(94, 14) DIB_ADD(95, 15)
+// DIB_ACC_FMA16: the same loop with ONE packed fused multiply-add per register (one rounding per tap
+// instead of two): half the tap arithmetic, not the reference's arithmetic.
+#define DIB_FMADD_A                                                                                         \
+  DIB_FMA(64, 0) DIB_FMA(65, 1) DIB_FMA(66, 2) DIB_FMA(67, 3) DIB_FMA(68, 4) DIB_FMA(69, 5) DIB_FMA(70, 6) DIB_FMA(71, 7) \
+  DIB_FMA(72, 8) DIB_FMA(73, 9) DIB_FMA(74, 10) DIB_FMA(75, 11) DIB_FMA(76, 12) DIB_FMA(77, 13) DIB_FMA(78, 14) DIB_FMA(79, 15)
+#define DIB_FMADD_B                                                                                         \
+  DIB_FMA(80, 0) DIB_FMA(81, 1) DIB_FMA(82, 2) DIB_FMA(83, 3) DIB_FMA(84, 4) DIB_FMA(85, 5) DIB_FMA(86, 6) DIB_FMA(87, 7) \
+  DIB_FMA(88, 8) DIB_FMA(89, 9) DIB_FMA(90, 10) DIB_FMA(91, 11) DIB_FMA(92, 12) DIB_FMA(93, 13) DIB_FMA(94, 14) DIB_FMA(95, 15)
+// HALF: row i of the tap sits in v[base + i]; it feeds the even accumulators (acc[i][0] = operand 2i)
+#define DIB_MADDH_A                                                                                         \
+  DIB_MUL(64) DIB_MUL(65) DIB_MUL(66) DIB_MUL(67) DIB_MUL(68) DIB_MUL(69) DIB_MUL(70) DIB_MUL(71) \
+  DIB_ADD(64, 0) DIB_ADD(65, 2) DIB_ADD(66, 4) DIB_ADD(67, 6) DIB_ADD(68, 8) DIB_ADD(69, 10) DIB_ADD(70, 12) DIB_ADD(71, 14)
+#define DIB_MADDH_B                                                                                         \
+  DIB_MUL(80) DIB_MUL(81) DIB_MUL(82) DIB_MUL(83) DIB_MUL(84) DIB_MUL(85) DIB_MUL(86) DIB_MUL(87) \
+  DIB_ADD(80, 0) DIB_ADD(81, 2) DIB_ADD(82, 4) DIB_ADD(83, 6) DIB_ADD(84, 8) DIB_ADD(85, 10) DIB_ADD(86, 12) DIB_ADD(87, 14)
+#define DIB_FMADDH_A                                                                                        \
+  DIB_FMA(64, 0) DIB_FMA(65, 2) DIB_FMA(66, 4) DIB_FMA(67, 6) DIB_FMA(68, 8) DIB_FMA(69, 10) DIB_FMA(70, 12) DIB_FMA(71, 14)
+#define DIB_FMADDH_B                                                                                        \
+  DIB_FMA(80, 0) DIB_FMA(81, 2) DIB_FMA(82, 4) DIB_FMA(83, 6) DIB_FMA(84, 8) DIB_FMA(85, 10) DIB_FMA(86, 12) DIB_FMA(87, 14)
+#define DIB_READ8(base)                                                                                      \
+  "v_mad_u32_u16 v96, %19, 1, %23\n\t"                                                                       \
+  "ds_read_b64 v[" #base ":" #base "+1], v96\n\tds_read_b64 v[" #base "+2:" #base "+3], v96 offset:768\n\t"   \
+  "ds_read_b64 v[" #base "+4:" #base "+5], v96 offset:1536\n\tds_read_b64 v[" #base "+6:" #base "+7], v96 offset:2304\n\t" \
+  "ds_read_b64 v[" #base "+8:" #base "+9], v96 offset:3072\n\tds_read_b64 v[" #base "+10:" #base "+11], v96 offset:3840\n\t" \
+  "ds_read_b64 v[" #base "+12:" #base "+13], v96 offset:4608\n\tds_read_b64 v[" #base "+14:" #base "+15], v96 offset:5376\n\t"
+#define DIB_READ8H(base)                                                                                     \
+  "v_mad_u32_u16 v96, %19, 1, %23\n\t"                                                                       \
+  "ds_read_b32 v[" #base "], v96\n\tds_read_b32 v[" #base "+1], v96 offset:768\n\t"                           \
+  "ds_read_b32 v[" #base "+2], v96 offset:1536\n\tds_read_b32 v[" #base "+3], v96 offset:2304\n\t"            \
+  "ds_read_b32 v[" #base "+4], v96 offset:3072\n\tds_read_b32 v[" #base "+5], v96 offset:3840\n\t"            \
+  "ds_read_b32 v[" #base "+6], v96 offset:4608\n\tds_read_b32 v[" #base "+7], v96 offset:5376\n\t"
+#define DIB_NEXTTAP "s_load_dword %20, %22, %16\n\ts_add_u32 %16, %16, 4\n\t"
+
+// acc[i][0] / acc[i][1] (i = 0..7): the packed fp16 accumulators of this lane's 8 rows x 4 columns.
+// The loop opens with vmcnt(0): a window load whose value hipcc found no use for may still be in flight, and
+// hipcc is free to have put its destination into a register clobbered here; it waits before ITS OWN next write
+// to such a register, but not before this asm's.
+template <bool FUSED, bool HALF>
+__device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+  // cnt = taps left minus one: the borrow of its decrement ends the loop (n >= 1 in every segment)
+  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
+  unsigned sA, sB, sC, st;
+  unsigned a[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[2 * i] = __builtin_bit_cast(unsigned, acc[i][0]); a[2 * i + 1] = __builtin_bit_cast(unsigned, acc[i][1]); }
+#define DIB_R8_ASM(WAIT0, RD_A, RD_B, ARITH_A, ARITH_B) \
+  asm volatile( \
+      /* prologue: ltap[t0] -> B, ltap[t0+1] -> C, data of tap t0 -> buffer A */ \
+      "s_load_dword %19, %22, %16\n\ts_add_u32 %16, %16, 4\n\t" DIB_NEXTTAP \
+      WAIT0 RD_A \
+      "Ldib_loop%=:\n\t" \
+      /* ---- tap in buffer A ---- */ \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t" \
+      RD_B DIB_NEXTTAP \
+      ARITH_A \
+      "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc1 Ldib_done%=\n\t" \
+      /* ---- tap in buffer B ---- */ \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %18, %19\n\ts_mov_b32 %19, %20\n\t" \
+      RD_A DIB_NEXTTAP \
+      ARITH_B \
+      "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc0 Ldib_loop%=\n\t" \
+      "Ldib_done%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)" \
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), \
+        "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+s"(toff), "+s"(cnt), "=&s"(sA), "=&s"(sB), \
+        "=&s"(sC), "=&s"(st) \
+      : "s"(ltaps), "v"(lane_addr) \
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", \
+        "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "scc", \
+        "memory")
+#define DIB_W_DRAIN "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+  if constexpr (HALF) {
+    if constexpr (FUSED) { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8H(64), DIB_READ8H(80), DIB_FMADDH_A, DIB_FMADDH_B); }
+    else { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8H(64), DIB_READ8H(80), DIB_MADDH_A, DIB_MADDH_B); }
+  } else {
+    if constexpr (FUSED) { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8(64), DIB_READ8(80), DIB_FMADD_A, DIB_FMADD_B); }
+    else { DIB_R8_ASM(DIB_W_DRAIN, DIB_READ8(64), DIB_READ8(80), DIB_MADD_A, DIB_MADD_B); }
+  }
+#undef DIB_W_DRAIN
+#undef DIB_R8_ASM
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { acc[i][0] = __builtin_bit_cast(h2, a[2 * i]); acc[i][1] = __builtin_bit_cast(h2, a[2 * i + 1]); }
+}
+#undef DIB_MUL
+#undef DIB_ADD
+#undef DIB_MADD_A
+#undef DIB_MADD_B
+#undef DIB_FMA
+#undef DIB_FMADD_A
+#undef DIB_FMADD_B
+#undef DIB_MADDH_A
+#undef DIB_MADDH_B
+#undef DIB_FMADDH_A
+#undef DIB_FMADDH_B
+#undef DIB_READ8
+#undef DIB_READ8H
+#undef DIB_NEXTTAP
+
+// DIB_ACC_FP32: acc32 = acc32 + float(P) * float(w), taps in the same order, ONE rounding to fp16 at the
+// store.  The product of two fp16 values is exact in fp32 (11 + 11 <= 24 significand bits), so fused
+// and unfused forms agree and the result is reproducible bit for bit on any IEEE fp32 machine (the
+// oracle restates it with numpy float32).  Plain C++: this mode trades the hand-scheduled loop for
+// accuracy (error vs exact arithmetic ~2^-12 relative instead of ~ntaps * 2^-12).
+template <int R>
+__device__ __forceinline__ void tap_loop_fp32(float (&acc)[R][4], const unsigned *__restrict__ ltaps, int t0, int n,
+                                              unsigned lane_addr) {
+#pragma clang fp contract(off)
+#pragma unroll 2
+  for (int t = t0; t < t0 + n; ++t) {
+    const unsigned lt = ltaps[t];
+    const float w = (float)__builtin_bit_cast(_Float16, (unsigned short)(lt >> 16));
+    const unsigned a = lane_addr + (lt & 0xffffu);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      typedef unsigned uvec2 __attribute__((ext_vector_type(2)));
+      const uvec2 q = *(const __attribute__((address_space(3))) uvec2 *)(size_t)(a + (unsigned)(i * PQ * 8));
+      const float p0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.x & 0xffffu));
+      const float p1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.x >> 16));
+      const float p2 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.y & 0xffffu));
+      const float p3 = (float)__builtin_bit_cast(_Float16, (unsigned short)(q.y >> 16));
+      // explicit fma: the product is exact in fp32, so fused == unfused bit for bit, and hipcc can fold
+      // the fp16 -> fp32 conversions of both factors into v_fma_mix_f32
+      acc[i][0] = __builtin_fmaf(p0, w, acc[i][0]); acc[i][1] = __builtin_fmaf(p1, w, acc[i][1]);
+      acc[i][2] = __builtin_fmaf(p2, w, acc[i][2]); acc[i][3] = __builtin_fmaf(p3, w, acc[i][3]);
+    }
+  }
+}
+
+// Diagnostic stamps (nullptr in every product launch): shader-clock readings of lane 0 of wave 0.
+__device__ __forceinline__ void stamp(unsigned long long *dbg, int slot) {
+  if (dbg && threadIdx.x == 0) dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = __builtin_readcyclecounter();
+}
+
+// Wave-uniform buffer descriptor of one channel plane (base, byte size): loads and stores then take
+// a 32-bit per-lane byte offset (voffset) plus a scalar row offset (soffset) -- no 64-bit address
+// arithmetic on the vector ALU, which the arithmetic of the co-resident waves keeps busy.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *img_base, int ch, int H, int W) {
+  const unsigned long long a = (unsigned long long)img_base + (unsigned long long)ch * H * W * 2ull;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, H * W * 2, 0x00020000);
+}
+
+constexpr int NW = 4;                       // waves per workgroup
+constexpr int R = TH / NW;                  // rows per lane (8)
+constexpr int G = (LROWS + NW - 1) / NW;    // LDS rows a wave fills (12): all of them in ONE batch of loads
+
+// The window of one (tile, tap segment) as a wave sees it: what to load, and later what to write to LDS.
+struct Window {
+  int t0, n;          // taps of the segment
+  int rf, rl, cmin, cmax;
+};
+__device__ __forceinline__ Window window_of(const uint4 seg) {
+  Window w;
+  w.t0 = seg.x; w.n = (int)(seg.y - seg.x);
+  w.rf = seg.z >> 8; w.rl = seg.z & 255; w.cmin = seg.w >> 8; w.cmax = seg.w & 255;
+  return w;
+}
+
+// Branch-free form of map_coord (dib_common.h) for the fill below: same mapping, `zero` = the read is a zero fill.
+__device__ __forceinline__ int map_coord_sel(int s, int n, int pa, int pb, int mode, bool &zero) {
+  s = (s == -pa) ? n + pb : s;                                    // torch.roll's wrap row / column
+  const int a = s < 0 ? -s : s;
+  const int refl = a > n - 1 ? 2 * (n - 1) - a : a;
+  const int m = mode == PAD_REFLECT ? refl : s;
+  zero = mode == PAD_ZERO && (s < 0 || s > n - 1);
+  return min(max(m, 0), n - 1);
+}
+
+// ---- fill, part 1: issue this wave's G x 5 window loads ---------------------------------------------------------
+// Per LDS row the five values P[lane + 64k] (word j and word j+64 share three).  The values stay in flight in v[][];
+// zmask collects the zero-fill flags (PAD_ZERO images only): bit k = column k of this lane, bit 8+g = row g of this
+// wave.  Address generation is the expensive part of a fill (a CU has ONE scalar unit for its twelve waves), so
+// windows that lie inside the image -- all but the border tiles -- take the short forms: one multiply and eleven
+// adds for the rows, one vector offset plus compile-time immediates for the columns.
+template <int G>
+__device__ __forceinline__ void issue_window_loads(unsigned (&v)[G][5], unsigned &zmask, const __amdgpu_buffer_rsrc_t in_rsrc,
+                                                   const Window &w, int x0, int y0, int H, int W, int K, int mode, int lane, int qb) {
+  const int pb = K / 2 - 1, pa = K / 2;
+  const int w2 = W * 2;
+  unsigned coff[5];
+  int soff[G];
+  zmask = 0;
+  const int c_first = x0 + pb - w.cmax;  // virtual column of P[0]
+  const int r_first = y0 + pb - w.rl;    // virtual row of the window's first LDS row
+  const bool zero_mode = mode == PAD_ZERO;
+  if (!zero_mode && c_first >= 0 && c_first + 63 + 256 <= W - 1) {
+    const unsigned c0 = 2u * (unsigned)(c_first + lane);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) coff[k] = c0 + 128u * k;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      bool z;
+      coff[k] = 2u * (unsigned)map_coord_sel(c_first + lane + 64 * k, W, pa, pb, mode, z);
+      zmask |= z ? 1u << k : 0u;
+    }
+  }
+  if (!zero_mode && r_first >= 0 && r_first + LROWS - 1 <= H - 1) {
+    const int s0 = (r_first + qb) * w2;
+#pragma unroll
+    for (int g = 0; g < G; ++g) soff[g] = s0 + g * w2;
+  } else {
+    const int nrows = TH + (w.rl - w.rf);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      bool zr;
+      // rows past the window's end repeat its last row: loaded and written, read by no tap
+      const int sr = map_coord_sel(r_first + min(qb + g, nrows - 1), H, pa, pb, mode, zr);
+      zmask |= zr ? 1u << (8 + g) : 0u;
+      soff[g] = sr * w2;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int so = __builtin_amdgcn_readfirstlane(soff[g]);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[g][k] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
+  }
+}
+
+// ---- fill, part 2: the loaded values -> LDS words {P[j], P[j+64], P[j+128], P[j+192]} ---------------------
+// word j from c0..c3, word j+64 from c1..c4 (only lanes below the segment's column extent have one).
+// wp: LDS byte address of this lane's word in this wave's first row.
+typedef unsigned uvec2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uvec2_t lds_u2;
+template <bool MASKED, int G>
+__device__ __forceinline__ void write_window_rows(unsigned wp, unsigned (&v)[G][5], unsigned zmask, bool second) {
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    // The values were loaded an iteration ago and must stay 60 separate registers in flight until here: without
+    // this fence hipcc hoists the packing below across the loop's back edge to right behind the loads (halving its
+    // live registers) and waits for every load there -- before the tap loop the loads were meant to hide behind.
+    asm volatile("" : "+v"(v[g][0]), "+v"(v[g][1]), "+v"(v[g][2]), "+v"(v[g][3]), "+v"(v[g][4]));
+    if (MASKED) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        if (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u)) v[g][k] = 0;
+    }
+    const unsigned w0 = v[g][0] | (v[g][1] << 16), w1 = v[g][2] | (v[g][3] << 16);
+    *(lds_u2 *)(size_t)(wp + (unsigned)(g * PQ * 8)) = uvec2_t{w0, w1};
+    // {c1, c2} and {c3, c4}: funnel shifts of the words above (one VALU instruction each)
+    if (second)
+      *(lds_u2 *)(size_t)(wp + (unsigned)((g * PQ + 64) * 8)) = uvec2_t{__builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(v[g][4], w1, 16)};
+  }
+}
+template <int G>
+__device__ __forceinline__ void write_window(unsigned wp, unsigned (&v)[G][5], unsigned zmask, bool second) {
+  if (__builtin_amdgcn_ballot_w64(zmask != 0) != 0) write_window_rows<true, G>(wp, v, zmask, second);   // PAD_ZERO images only
+  else write_window_rows<false, G>(wp, v, zmask, second);
+}
+
+// ---- store: lane owns columns x0 + lane + 64k ---------------------------------------------------------
+// No execution masks and no branches: the hardware drops a buffer store whose per-lane offset lies past the
+// descriptor's range.  Lanes whose column is outside the image get an out-of-range offset once per tile; a row
+// below the image (bottom tiles of an image whose height is not a multiple of 32) is stored through a descriptor of
+// range zero.  Always exactly 4 x R store instructions: the look-ahead of the strip loop relies on that count
+// (vector-memory operations retire in issue order; hipcc can only wait for "all but the last 32" if it is sure of the 32).
+template <int ACC, int R>
+__device__ __forceinline__ void store_tile(const h2 (&acc)[R][2], const float (&acc32)[R][4], void *out_base, int ch, int H, int W, int x0,
+                                           int y0, int lane, int wave) {
+  const unsigned long long pa = (unsigned long long)out_base + (unsigned long long)ch * H * W * 2ull;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pa), hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+  void *plane = (void *)(((unsigned long long)hi << 32) | lo);
+  const int w2 = W * 2;
+  const int xr = W - x0 - lane;  // columns remaining for this lane
+  const unsigned voff = 2u * (unsigned)(x0 + lane), oob = 0x7ffffff0u;
+  const unsigned vo0 = xr > 0 ? voff : oob, vo1 = xr > 64 ? voff + 128u : oob, vo2 = xr > 128 ? voff + 256u : oob,
+                 vo3 = xr > 192 ? voff + 384u : oob;
+  const int yb = y0 + wave * R;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(plane, 0, yb + i < H ? H * w2 : 0, 0x00020000);
+    const int soff = (yb + i) * w2;
+    // halves are extracted with integer ops: hipcc (ROCm 7.2) stored the LOW half twice when the
+    // high element of the fp16x2 accumulator was taken with a vector subscript
+    unsigned a = __builtin_bit_cast(unsigned, acc[i][0]), b = __builtin_bit_cast(unsigned, acc[i][1]);
+    if constexpr (ACC == DIB_ACC_FP32) {
+      a = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][0]) |
+          ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][1]) << 16);
+      b = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][2]) |
+          ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc32[i][3]) << 16);
+    }
+    __builtin_amdgcn_raw_buffer_store_b16((short)(a & 0xffffu), out_rsrc, vo0, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b16((short)(a >> 16), out_rsrc, vo1, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b16((short)(b & 0xffffu), out_rsrc, vo2, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b16((short)(b >> 16), out_rsrc, vo3, soff, 0);
+  }
+}
+
+// =============================================================================================================
+// The tiled kernel: one workgroup = one (image, channel, 256 x 32 tile); fill -> taps -> store, the latencies of one
+// workgroup's phases hidden by the other three workgroups of its CU.
+// Round 2 built the alternative in full -- a PERSISTENT kernel (3 workgroups per CU for the whole launch) that issues
+// the window loads of tile n+1 before the tap loop of tile n (60 values in flight per lane), defers the stores of
+// tile n-1 behind the next barrier so they do not sit in front of those loads in the in-order vmcnt queue, runs a
+// static snake schedule over the per-XCD lists, and keeps only tile indices in SGPRs -- in a 4-wave x 8-row and an
+// 8-wave x 4-row form, both bit-identical to this kernel (scratch/blur_stream_experiment.hip, scratch/stamps_stream.py).
+// Measured on the BASELINE batch: 62.6 us (4 x 8, tap loops at raised priority) and 70.8 us (8 x 4) against 52 us
+// here.  Why: (1) the look-ahead costs 60 + 16 registers, i.e. one wave per SIMD (168 registers, 3 waves), and the
+// packed-fp16 issue rate of a SIMD grows with the number of waves that are inside tap loops at the same time
+// (scratch/ubench/ub_clk.hip: 5.1 / 4.4 / 3.0 / 2.6 cycles per instruction with 1 / 2 / 3 / 8 waves); (2) a dynamic
+// tile queue is not affordable: a returning device-scope atomic took ~10 us under the kernel's own load, twice a tap
+// loop (139 us per launch with tickets drawn one tile ahead); (3) with static shares the slowest workgroup ran 25 %
+// longer than the mean.  The hardware dispatcher of THIS kernel is the better tile queue.
+// =============================================================================================================
+template <int ACC>
+__device__ __forceinline__ void blur_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx,
+                                              int ty, uint2 *lds, unsigned long long *dbg) {
+#pragma clang fp contract(off)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = d.H, W = d.W;
+  const int mode = pad_mode_for(K, H, W);
+  const int nsegs = tab[HDR_NSEGS];
+  const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
+  const unsigned long long la = (unsigned long long)(tab + table_ltaps_off(K));
+  const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
+  const int x0 = tx * TILE_W;
+  const bool half = W - x0 <= 128;   // every valid column lies in the tile's first 128: the HALF tap loop
+  const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(d.in, ch, H, W);
+
+  h2 acc[R][2];
+  float acc32[R][4];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    acc[i][0] = h2{0, 0}; acc[i][1] = h2{0, 0};
+    acc32[i][0] = acc32[i][1] = acc32[i][2] = acc32[i][3] = 0.f;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+  const unsigned lane_addr = lds0 + (unsigned)((wave * R) * PQ + lane) * 8u;
+  const int qb = wave * G;
+  const unsigned wp = lds0 + (unsigned)(qb * PQ + lane) * 8u;
+  unsigned v[G][5];
+  unsigned zmask;
+
+  stamp(dbg, 0);
+  const int y0 = ty * TH;
+  for (int sg = 0; sg < nsegs; ++sg) {
+    const Window w = window_of(segs[sg]);
+    issue_window_loads(v, zmask, in_rsrc, w, x0, y0, H, W, K, mode, lane, qb);
+    if (sg > 0) __syncthreads();  // every wave is done reading the previous segment's window
+    write_window(wp, v, zmask, lane < w.cmax - w.cmin);
+    __syncthreads();
+    if (sg == 0) stamp(dbg, 1);
+    // the table pointer itself (kernel-argument derived, provably uniform): hipcc then fetches the ltap words
+    // with scalar loads; a pointer rebuilt from an integer would go through per-lane flat loads
+    if constexpr (ACC == DIB_ACC_FP32) tap_loop_fp32<R>(acc32, reinterpret_cast<const unsigned *>(tab + table_ltaps_off(K)), w.t0, w.n, lane_addr);
+    else if (half) tap_loop_r8<ACC == DIB_ACC_FMA16, true>(acc, ltaps, w.t0, w.n, lane_addr);
+    else tap_loop_r8<ACC == DIB_ACC_FMA16, false>(acc, ltaps, w.t0, w.n, lane_addr);
+    if (sg == 0) stamp(dbg, 2);
+  }
+  store_tile<ACC, R>(acc, acc32, d.out, ch, H, W, x0, y0, lane, wave);
+  stamp(dbg, 3);
+}
+
+// Tile order.  Workgroups with equal blockIdx % 8 share an XCD (and its 4 MB L2); hardware hands consecutive ids
+// to different XCDs, so with a flat tile order no two neighbouring tiles ever share an L2 and every halo row comes
+// from HBM again (measured 1.85 x the algorithmic traffic).  Instead the tiles of every image are cut into eight
+// contiguous bands, band x of every image forming XCD x's LIST: neighbouring tiles run on one XCD close in time
+// (halo rows hit in L2), and every XCD still gets an equal share of every image, so PSFs of different tap counts do
+// not unbalance the XCDs.  (A performance choice only: any tile order gives the same output.)
+// Grid: y = image (descriptor order: heaviest first), x = 8 t + list.  The image index comes with the workgroup, so the
+// prologue's chain of dependent scalar loads is descriptor -> table header / first segment (two round trips; a lookup
+// through a flattened tile index cost a third).  band_entry: entry t of list x of an image with T tiles -> tile index
+// inside the image; false past the end of the band (the grid's x extent is 8 x the longest band of the launch).
+__device__ __forceinline__ bool band_entry(int T, int x, int t, int &local) {
+  const int lo = (x * T) >> 3, hi = ((x + 1) * T) >> 3;
+  local = lo + t;
+  return t < hi - lo;
+}
+
+// =============================================================================================================
+// Narrow shape: 128 x 32 tiles.  Lane l owns columns x0 + l and x0 + l + 64 (ONE packed register per row), the LDS
+// word is 4 bytes {P[j], P[j+64]} and the window 48 rows x 96 words x 4 B = 18 KB: seven workgroups per CU instead of
+// four.  The kernel is a closed system -- a CU's slots each run dispatch -> prologue -> fill -> taps -> store in
+// sequence, and its time is (tiles per slot) x (latency of one workgroup) -- so slots are what buys throughput:
+// measured on the BASELINE batch 3 / 4 slots gave 61 / 51 us with the 256-wide tile.  Costs: 1.25 x instead of
+// 1.125 x halo columns, and twice the workgroups (their fixed cost is ~2.4 us each).
+// =============================================================================================================
+constexpr int NTILE_W = 128;
+constexpr int NPITCH = WIN_PITCH * 4;         // bytes per LDS row (384)
+constexpr int NLDS_BYTES = LROWS * NPITCH;    // 18,432 B
+static_assert(NPITCH == 384, "the asm below hard-codes the LDS row pitch");
+
+// The r8 tap loop on 4-byte words: the ltap word carries the byte offset of the 8-byte-word layout, so it is halved
+// (s_bfe_u32: bits 15..1) -- one more scalar instruction per tap.  Buffers v[32:39] / v[40:47], address v48.
+// Operands: %0-%7 accumulators, %8 byte offset of the next ltap, %9 taps left, %10 A, %11 B, %12 C, %13 temp, %14 ltaps, %15 lane base.
+#define DIBN_MUL(b) "v_pk_mul_f16 v" #b ", %10, v" #b " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+#define DIBN_ADD(b, i) "v_pk_add_f16 %" #i ", %" #i ", v" #b "\n\t"
+#define DIBN_FMA(b, i) "v_pk_fma_f16 %" #i ", %10, v" #b ", %" #i " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define DIBN_MADD_A DIBN_MUL(32) DIBN_MUL(33) DIBN_MUL(34) DIBN_MUL(35) DIBN_MUL(36) DIBN_MUL(37) DIBN_MUL(38) DIBN_MUL(39) \
+  DIBN_ADD(32, 0) DIBN_ADD(33, 1) DIBN_ADD(34, 2) DIBN_ADD(35, 3) DIBN_ADD(36, 4) DIBN_ADD(37, 5) DIBN_ADD(38, 6) DIBN_ADD(39, 7)
+#define DIBN_MADD_B DIBN_MUL(40) DIBN_MUL(41) DIBN_MUL(42) DIBN_MUL(43) DIBN_MUL(44) DIBN_MUL(45) DIBN_MUL(46) DIBN_MUL(47) \
+  DIBN_ADD(40, 0) DIBN_ADD(41, 1) DIBN_ADD(42, 2) DIBN_ADD(43, 3) DIBN_ADD(44, 4) DIBN_ADD(45, 5) DIBN_ADD(46, 6) DIBN_ADD(47, 7)
+#define DIBN_FMADD_A DIBN_FMA(32, 0) DIBN_FMA(33, 1) DIBN_FMA(34, 2) DIBN_FMA(35, 3) DIBN_FMA(36, 4) DIBN_FMA(37, 5) DIBN_FMA(38, 6) DIBN_FMA(39, 7)
+#define DIBN_FMADD_B DIBN_FMA(40, 0) DIBN_FMA(41, 1) DIBN_FMA(42, 2) DIBN_FMA(43, 3) DIBN_FMA(44, 4) DIBN_FMA(45, 5) DIBN_FMA(46, 6) DIBN_FMA(47, 7)
+#define DIBN_READ(base)                                                                                      \
+  "s_bfe_u32 %13, %11, 0xf0001\n\tv_add_u32 v48, %13, %15\n\t"                                                \
+  "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+1], v48 offset:384\n\t"                           \
+  "ds_read_b32 v[" #base "+2], v48 offset:768\n\tds_read_b32 v[" #base "+3], v48 offset:1152\n\t"             \
+  "ds_read_b32 v[" #base "+4], v48 offset:1536\n\tds_read_b32 v[" #base "+5], v48 offset:1920\n\t"            \
+  "ds_read_b32 v[" #base "+6], v48 offset:2304\n\tds_read_b32 v[" #base "+7], v48 offset:2688\n\t"
+#define DIBN_NEXTTAP "s_load_dword %12, %14, %8\n\ts_add_u32 %8, %8, 4\n\t"
+template <bool FUSED>
+__device__ __forceinline__ void tap_loop_narrow(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
+  unsigned sA, sB, sC, st;
+  unsigned a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
+#define DIB_RN_ASM(ARITH_A, ARITH_B) \
+  asm volatile( \
+      "s_load_dword %11, %14, %8\n\ts_add_u32 %8, %8, 4\n\t" DIBN_NEXTTAP \
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIBN_READ(32) \
+      "Ldibn_loop%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
+      DIBN_READ(40) DIBN_NEXTTAP \
+      ARITH_A \
+      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 Ldibn_done%=\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
+      DIBN_READ(32) DIBN_NEXTTAP \
+      ARITH_B \
+      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc0 Ldibn_loop%=\n\t" \
+      "Ldibn_done%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)" \
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+s"(toff), "+s"(cnt), \
+        "=&s"(sA), "=&s"(sB), "=&s"(sC), "=&s"(st) \
+      : "s"(ltaps), "v"(lane_addr) \
+      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "scc", \
+        "memory")
+  if constexpr (FUSED) { DIB_RN_ASM(DIBN_FMADD_A, DIBN_FMADD_B); } else { DIB_RN_ASM(DIBN_MADD_A, DIBN_MADD_B); }
+#undef DIB_RN_ASM
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
+}
+
+template <int ACC>
+__device__ __forceinline__ void blur_narrow_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
+                                                     unsigned *lds) {
+#pragma clang fp contract(off)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = d.H, W = d.W, w2 = W * 2;
+  const int mode = pad_mode_for(K, H, W);
+  const int pb = K / 2 - 1, pa = K / 2;
+  const int nsegs = tab[HDR_NSEGS];
+  const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
+  const unsigned long long la = (unsigned long long)(tab + table_ltaps_off(K));
+  const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
+  const int x0 = tx * NTILE_W, y0 = ty * TH;
+  const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(d.in, ch, H, W);
+  h2 acc[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) acc[i] = h2{0, 0};
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+  const unsigned lane_addr = lds0 + (unsigned)((wave * R) * NPITCH + lane * 4);
+  const int qb = wave * G;
+  const unsigned wp = lds0 + (unsigned)(qb * NPITCH + lane * 4);
+  typedef __attribute__((address_space(3))) unsigned lds_u1;
+
+  for (int sg = 0; sg < nsegs; ++sg) {
+    const Window w = window_of(segs[sg]);
+    // ---- fill: per LDS row the three values P[lane + 64k] ---------------------------------------------------------
+    unsigned v[G][3], coff[3];
+    int soff[G];
+    unsigned zmask = 0;
+    const int c_first = x0 + pb - w.cmax, r_first = y0 + pb - w.rl;
+    const bool zero_mode = mode == PAD_ZERO;
+    if (!zero_mode && c_first >= 0 && c_first + 63 + 128 <= W - 1) {
+      const unsigned c0 = 2u * (unsigned)(c_first + lane);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) coff[k] = c0 + 128u * k;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        bool z;
+        coff[k] = 2u * (unsigned)map_coord_sel(c_first + lane + 64 * k, W, pa, pb, mode, z);
+        zmask |= z ? 1u << k : 0u;
+      }
+    }
+    if (!zero_mode && r_first >= 0 && r_first + LROWS - 1 <= H - 1) {
+      const int s0 = (r_first + qb) * w2;
+#pragma unroll
+      for (int g = 0; g < G; ++g) soff[g] = s0 + g * w2;
+    } else {
+      const int nrows = TH + (w.rl - w.rf);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        bool zr;
+        const int sr = map_coord_sel(r_first + min(qb + g, nrows - 1), H, pa, pb, mode, zr);
+        zmask |= zr ? 1u << (8 + g) : 0u;
+        soff[g] = sr * w2;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int so = __builtin_amdgcn_readfirstlane(soff[g]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[g][k] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
+    }
+    if (sg > 0) __syncthreads();  // every wave is done reading the previous window
+    const bool second = lane < w.cmax - w.cmin;
+    const bool masked = __builtin_amdgcn_ballot_w64(zmask != 0) != 0;   // PAD_ZERO images only
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (masked) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u)) v[g][k] = 0;
+      }
+      const unsigned w0 = v[g][0] | (v[g][1] << 16);
+      *(lds_u1 *)(size_t)(wp + (unsigned)(g * NPITCH)) = w0;
+      if (second) *(lds_u1 *)(size_t)(wp + (unsigned)(g * NPITCH + 256)) = __builtin_amdgcn_alignbit(v[g][2], w0, 16);
+    }
+    __syncthreads();
+    tap_loop_narrow<ACC == DIB_ACC_FMA16>(acc, ltaps, w.t0, w.n, lane_addr);
+  }
+  // ---- store (see store_tile: out-of-range lanes get an out-of-range offset, rows below the image a null descriptor) ----
+  {
+    const unsigned long long pa2 = (unsigned long long)d.out + (unsigned long long)ch * H * W * 2ull;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pa2), hi = __builtin_amdgcn_readfirstlane((unsigned)(pa2 >> 32));
+    void *plane = (void *)(((unsigned long long)hi << 32) | lo);
+    const int xr = W - x0 - lane;
+    const unsigned voff = 2u * (unsigned)(x0 + lane), oob = 0x7ffffff0u;
+    const unsigned vo0 = xr > 0 ? voff : oob, vo1 = xr > 64 ? voff + 128u : oob;
+    const int yb = y0 + wave * R;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(plane, 0, yb + i < H ? H * w2 : 0, 0x00020000);
+      const int so = (yb + i) * w2;
+      const unsigned a = __builtin_bit_cast(unsigned, acc[i]);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a & 0xffffu), out_rsrc, vo0, so, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a >> 16), out_rsrc, vo1, so, 0);
+    }
+  }
+}
+
+// =============================================================================================
+// "Quad" shape: 128-wide tiles like the narrow shape, but a lane owns FOUR columns of FOUR rows --
+// lane = 32 h + j computes columns {j, j+32, j+64, j+96} of rows 4h .. 4h+3 of its wave's 8 rows -- and the
+// window is stored as 8-byte elements  e[k] = {P[k], P[k+32] | P[k+64], P[k+96]}  (k = 0 .. 31 + SEG_COLS),
+// so that one tap is 4 x ds_read_b64 per lane instead of 8 x ds_read_b32: the LDS serves 256 B per clock for
+// 8-byte reads and 128 B for 4-byte ones (MI355X_MICROARCH.md, LDS table), and the narrow shape's tap phase ran at
+// the LDS's rate, not the vector ALU's (16 LDS cycles against ~42 ALU cycles per wave-tap, four SIMDs sharing one LDS).
+// Element k + dcol is 8-byte aligned for every tap column, and the 32 lanes of an LDS lane group read 32
+// consecutive elements = all 64 banks once.  44 rows x 56 elements x 8 B = 19,712 B: eight workgroups per CU.
+// =============================================================================================
+constexpr int QTILE_W = 128;
+constexpr int QPITCH = QUAD_PITCH * 8;        // bytes per LDS row (448)
+constexpr int QLDS_BYTES = LROWS * QPITCH;    // 19,712 B
+static_assert(QPITCH == 448, "the asm below hard-codes the LDS row pitch");
+static_assert(LROWS % NW == 0, "every wave fills the same number of window rows");
+
+// Tap loop of the quad shape: 4 x 8-byte reads per tap, rows i = 0..3 land in v[base+2i : base+2i+1] = the operands of
+// accumulators 2i (columns j, j+32) and 2i+1 (columns j+64, j+96); the LDS address is one v_mad_u32_u16 (low 16 bits of
+// the ltap word + lane base).  Same arithmetic and the same one-tap LDS look-ahead as tap_loop_narrow; the scalar side
+// is leaner because every instruction a wave issues costs launch time here (measured by padding the loop: +0.24 us per
+// million scalar, +0.69 per million vector, +1.25 per million LDS instructions): the ltap words
+// arrive two at a time (s_load_dwordx2) into three fixed register pairs P = s[36:37], Q = s[38:39], R = s[40:41] that the
+// 6-way unrolled body addresses by name, so nothing is moved between "current / next / in flight" registers, and the body
+// carries NO per-tap exit test: a segment of n taps is entered at position (6 - n % 6) % 6 of the body, so that it ends
+// with a pass (Duff's device; an odd entry position takes its first tap from the high word of the pair one word
+// earlier -- the word in front of a table's list is allocated).  Per tap: 1 wait + 1/2 load + 1/2 add + 1/3
+// subtract-and-branch instead of 7 scalar instructions.  A pair is reloaded in the tap after its last use and first used
+// three taps later (with two pairs and one tap of cover the waits ran into the scalar loads: no faster than the old loop).
+//   position 0: load R <- next pair | read Y at offset(P.hi) | multiply-add X by weight(P.lo)
+//   position 1:                       read X at offset(Q.lo) | multiply-add Y by weight(P.hi)
+//   position 2: load P <- next pair | read Y at offset(Q.hi) | multiply-add X by weight(Q.lo)
+//   position 3:                       read X at offset(R.lo) | multiply-add Y by weight(Q.hi)
+//   position 4: load Q <- next pair | read Y at offset(R.hi) | multiply-add X by weight(R.lo)
+//   position 5:                       read X at offset(P.lo) | multiply-add Y by weight(R.hi) | next pass?
+// Operands: %0-%7 accumulators, %8 byte offset of the next ltap pair (from ltaps - 4), %9 n - 1, then passes left,
+// %10 / %11 scalar temporaries, %12 ltaps - 4, %13 lane base.
+#define DIBQ_MUL(b, W) "v_pk_mul_f16 v" #b ", " W ", v" #b " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+#define DIBQ_FMA(b, i, W) "v_pk_fma_f16 %" #i ", " W ", v" #b ", %" #i " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define DIBQ_MADD_X(W) DIBQ_MUL(32, W) DIBQ_MUL(33, W) DIBQ_MUL(34, W) DIBQ_MUL(35, W) DIBQ_MUL(36, W) DIBQ_MUL(37, W) DIBQ_MUL(38, W) DIBQ_MUL(39, W) \
+  DIBN_ADD(32, 0) DIBN_ADD(33, 1) DIBN_ADD(34, 2) DIBN_ADD(35, 3) DIBN_ADD(36, 4) DIBN_ADD(37, 5) DIBN_ADD(38, 6) DIBN_ADD(39, 7)
+#define DIBQ_MADD_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(41, W) DIBQ_MUL(42, W) DIBQ_MUL(43, W) DIBQ_MUL(44, W) DIBQ_MUL(45, W) DIBQ_MUL(46, W) DIBQ_MUL(47, W) \
+  DIBN_ADD(40, 0) DIBN_ADD(41, 1) DIBN_ADD(42, 2) DIBN_ADD(43, 3) DIBN_ADD(44, 4) DIBN_ADD(45, 5) DIBN_ADD(46, 6) DIBN_ADD(47, 7)
+#define DIBQ_FMADD_X(W) DIBQ_FMA(32, 0, W) DIBQ_FMA(33, 1, W) DIBQ_FMA(34, 2, W) DIBQ_FMA(35, 3, W) DIBQ_FMA(36, 4, W) DIBQ_FMA(37, 5, W) DIBQ_FMA(38, 6, W) DIBQ_FMA(39, 7, W)
+#define DIBQ_FMADD_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(41, 1, W) DIBQ_FMA(42, 2, W) DIBQ_FMA(43, 3, W) DIBQ_FMA(44, 4, W) DIBQ_FMA(45, 5, W) DIBQ_FMA(46, 6, W) DIBQ_FMA(47, 7, W)
+#define DIBQ_READ(base, OFF)                                                                                 \
+  "v_mad_u32_u16 v48, " OFF ", 1, %13\n\t"                                                                    \
+  "ds_read_b64 v[" #base ":" #base "+1], v48\n\tds_read_b64 v[" #base "+2:" #base "+3], v48 offset:448\n\t"    \
+  "ds_read_b64 v[" #base "+4:" #base "+5], v48 offset:896\n\tds_read_b64 v[" #base "+6:" #base "+7], v48 offset:1344\n\t"
+// HALF variant: a tile with at most 64 valid columns (the right-hand edge of an image whose width is not a multiple of
+// 128: 1333 = 10 x 128 + 53) only needs the first word {P[k], P[k+32]} of every element: 4-byte reads, 4 + 4 instead of
+// 8 + 8 arithmetic instructions per tap, on the even registers / accumulators.
+#define DIBQ_READH(base, OFF)                                                                                \
+  "v_mad_u32_u16 v48, " OFF ", 1, %13\n\t"                                                                    \
+  "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+2], v48 offset:448\n\t"                            \
+  "ds_read_b32 v[" #base "+4], v48 offset:896\n\tds_read_b32 v[" #base "+6], v48 offset:1344\n\t"
+#define DIBQ_MADDH_X(W) DIBQ_MUL(32, W) DIBQ_MUL(34, W) DIBQ_MUL(36, W) DIBQ_MUL(38, W) DIBN_ADD(32, 0) DIBN_ADD(34, 2) DIBN_ADD(36, 4) DIBN_ADD(38, 6)
+#define DIBQ_MADDH_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(42, W) DIBQ_MUL(44, W) DIBQ_MUL(46, W) DIBN_ADD(40, 0) DIBN_ADD(42, 2) DIBN_ADD(44, 4) DIBN_ADD(46, 6)
+#define DIBQ_FMADDH_X(W) DIBQ_FMA(32, 0, W) DIBQ_FMA(34, 2, W) DIBQ_FMA(36, 4, W) DIBQ_FMA(38, 6, W)
+#define DIBQ_FMADDH_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(42, 2, W) DIBQ_FMA(44, 4, W) DIBQ_FMA(46, 6, W)
+#define DIBQ_LOAD(PAIR) "s_load_dwordx2 " PAIR ", %12, %8\n\ts_add_u32 %8, %8, 8\n\t"
+template <bool FUSED, bool HALF>
+__device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
+  unsigned a[8], t1, t2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
+#define DIBQ_WAIT "s_waitcnt lgkmcnt(0)\n\t"
+#define DIB_RQ_ASM(RD, ARITH_X, ARITH_Y) \
+  asm volatile( \
+      /* %9 = n - 1 on entry: passes - 1 = (n - 1) / 6, entry position = 5 - (n - 1) % 6 */ \
+      "s_mul_i32 %10, %9, 0xaaab\n\ts_lshr_b32 %10, %10, 18\n\ts_mul_i32 %11, %10, 6\n\ts_sub_u32 %11, %9, %11\n\ts_mov_b32 %9, %10\n\t" \
+      /* %8 counts from one word in front of the tap list: an odd position's first tap is the HIGH word of its pair */ \
+      "s_cmp_eq_u32 %11, 4\n\ts_cbranch_scc1 Ldibq_e1%=\n\t" \
+      "s_cmp_eq_u32 %11, 2\n\ts_cbranch_scc1 Ldibq_e3%=\n\t" \
+      "s_cmp_eq_u32 %11, 0\n\ts_cbranch_scc1 Ldibq_e5%=\n\t" \
+      "s_add_u32 %8, %8, 4\n\t" \
+      "s_cmp_eq_u32 %11, 5\n\ts_cbranch_scc1 Ldibq_e0%=\n\t" \
+      "s_cmp_eq_u32 %11, 3\n\ts_cbranch_scc1 Ldibq_e2%=\n\t" \
+      "s_branch Ldibq_e4%=\n\t" \
+      "Ldibq_e5%=:\n\t" \
+      DIBQ_LOAD("s[40:41]") DIBQ_LOAD("s[36:37]") DIBQ_LOAD("s[38:39]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(40, "s41") "s_branch Ldibq_b5%=\n\t" \
+      "Ldibq_e0%=:\n\t" DIBQ_LOAD("s[36:37]") DIBQ_LOAD("s[38:39]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(32, "s36") "s_branch Ldibq_b0%=\n\t" \
+      "Ldibq_e1%=:\n\t" DIBQ_LOAD("s[36:37]") DIBQ_LOAD("s[38:39]") DIBQ_LOAD("s[40:41]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(40, "s37") "s_branch Ldibq_b1%=\n\t" \
+      "Ldibq_e2%=:\n\t" DIBQ_LOAD("s[38:39]") DIBQ_LOAD("s[40:41]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(32, "s38") "s_branch Ldibq_b2%=\n\t" \
+      "Ldibq_e3%=:\n\t" DIBQ_LOAD("s[38:39]") DIBQ_LOAD("s[40:41]") DIBQ_LOAD("s[36:37]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(40, "s39") "s_branch Ldibq_b3%=\n\t" \
+      "Ldibq_e4%=:\n\t" DIBQ_LOAD("s[40:41]") DIBQ_LOAD("s[36:37]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(32, "s40") "s_branch Ldibq_b4%=\n\t" \
+      "Ldibq_b0%=:\n\t" DIBQ_WAIT DIBQ_LOAD("s[40:41]") RD(40, "s37") ARITH_X("s36") \
+      "Ldibq_b1%=:\n\t" DIBQ_WAIT RD(32, "s38") ARITH_Y("s37") \
+      "Ldibq_b2%=:\n\t" DIBQ_WAIT DIBQ_LOAD("s[36:37]") RD(40, "s39") ARITH_X("s38") \
+      "Ldibq_b3%=:\n\t" DIBQ_WAIT RD(32, "s40") ARITH_Y("s39") \
+      "Ldibq_b4%=:\n\t" DIBQ_WAIT DIBQ_LOAD("s[38:39]") RD(40, "s41") ARITH_X("s40") \
+      "Ldibq_b5%=:\n\t" DIBQ_WAIT RD(32, "s36") ARITH_Y("s41") \
+      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc0 Ldibq_b0%=\n\t" \
+      "s_waitcnt lgkmcnt(0)" \
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+s"(toff), "+s"(cnt), \
+        "=&s"(t1), "=&s"(t2) \
+      : "s"(ltaps - 4), "v"(lane_addr) \
+      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", \
+        "s36", "s37", "s38", "s39", "s40", "s41", "scc", "memory")
+  if constexpr (FUSED && HALF) { DIB_RQ_ASM(DIBQ_READH, DIBQ_FMADDH_X, DIBQ_FMADDH_Y); }
+  else if constexpr (FUSED) { DIB_RQ_ASM(DIBQ_READ, DIBQ_FMADD_X, DIBQ_FMADD_Y); }
+  else if constexpr (HALF) { DIB_RQ_ASM(DIBQ_READH, DIBQ_MADDH_X, DIBQ_MADDH_Y); }
+  else { DIB_RQ_ASM(DIBQ_READ, DIBQ_MADD_X, DIBQ_MADD_Y); }
+#undef DIB_RQ_ASM
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
+}
+
+// {lo, hi} 16-bit values -> one dword.  As asm because hipcc zero-extends a 16-bit buffer load's result with a v_and
+// before any 32-bit use (the hardware already did), even when the user is v_perm_b32, which never looks at those bits:
+// a 16-bit asm operand is passed any-extended.
+__device__ __forceinline__ unsigned pack_lo16(short hi, short lo) {
+  unsigned r;
+  asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(0x05040100u));
+  return r;
+}
+
+template <int ACC>
+__device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
+                                                   unsigned *lds) {
+#pragma clang fp contract(off)
+  constexpr int GQ = LROWS / NW;              // LDS rows a wave fills (11)
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int H = d.H, W = d.W, w2 = W * 2;
+  const int mode = pad_mode_for(K, H, W);
+  const int pb = K / 2 - 1, pa = K / 2;
+  // second (and last) scalar round trip of the prologue: segment count and first segment, requested together.  Written
+  // out because hipcc turns these into vector loads + v_readfirstlane once an asm statement precedes them.
+  const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
+  int nsegs;
+  uint4 seg;
+  {
+    unsigned __int128 r;
+    asm volatile("s_load_dword %0, %2, 0x1c\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(nsegs), "=&s"(r) : "s"((unsigned long long)tab), "s"((unsigned long long)segs));
+    seg = make_uint4((unsigned)r, (unsigned)(r >> 32), (unsigned)(r >> 64), (unsigned)(r >> 96));
+  }
+  static_assert(HDR_NSEGS * 4 == 0x1c, "offset of the segment count in the asm above");
+  const unsigned long long la = (unsigned long long)(tab + table_ltaps_q_off(K));
+  const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
+  const int x0 = tx * QTILE_W, y0 = ty * TH;
+  const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(d.in, ch, H, W);
+  h2 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = h2{0, 0};
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+  const int qb = wave * GQ;
+  // Lane-derived values of the later phases are recomputed there from an opaque copy of the lane index (2-3 instructions):
+  // hoisted to here they would stay live across the 44 outstanding window loads and spill (64 registers = 8 waves / SIMD).
+  // (the lane index itself comes from v_mbcnt: no input register to keep either)
+  auto fresh_lane = [&]() { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; };
+  typedef unsigned lds_u2v __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) lds_u2v lds_u2;
+
+  for (int sg = 0; sg < nsegs; ++sg) {
+    if (sg > 0) seg = segs[sg];
+    const Window w = window_of(seg);
+    const int lane = fresh_lane();
+    // ---- fill: per LDS row the four values P[lane + 32 m] of element `lane` ----------------------------------------
+    short v[GQ][4];
+    unsigned coff[4];
+    int soff[GQ];
+    unsigned zmask = 0;
+    const int c_first = x0 + pb - w.cmax, r_first = y0 + pb - w.rl;
+    const bool zero_mode = mode == PAD_ZERO;
+    if (!zero_mode && c_first >= 0 && c_first + 63 + 96 <= W - 1) {
+      const unsigned c0 = 2u * (unsigned)(c_first + lane);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) coff[k] = c0 + 64u * k;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bool z;
+        coff[k] = 2u * (unsigned)map_coord_sel(c_first + lane + 32 * k, W, pa, pb, mode, z);
+        zmask |= z ? 1u << k : 0u;
+      }
+    }
+    if (!zero_mode && r_first >= 0 && r_first + LROWS - 1 <= H - 1) {
+      const int s0 = (r_first + qb) * w2;
+#pragma unroll
+      for (int g = 0; g < GQ; ++g) soff[g] = s0 + g * w2;
+    } else {
+      const int nrows = TH + (w.rl - w.rf);
+#pragma unroll
+      for (int g = 0; g < GQ; ++g) {
+        bool zr;
+        const int sr = map_coord_sel(r_first + min(qb + g, nrows - 1), H, pa, pb, mode, zr);
+        zmask |= zr ? 1u << (8 + g) : 0u;
+        soff[g] = sr * w2;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GQ; ++g) {
+      const int so = __builtin_amdgcn_readfirstlane(soff[g]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
+    }
+    if (sg > 0) __syncthreads();  // every wave is done reading the previous window
+    // Elements 0 .. 31 + column extent are read by the taps; writing all 56 of a row costs the same (an LDS store is
+    // priced per instruction), lanes 56-63 own no element.  The two 16-bit values of a word are merged by v_perm_b32
+    // straight from the load registers (the packing does not care what their high halves hold).
+    const bool masked = __builtin_amdgcn_ballot_w64(zmask != 0) != 0;   // PAD_ZERO images only
+    const int wl = fresh_lane();
+    const unsigned wp = lds0 + (unsigned)(qb * QPITCH + wl * 8);
+    if (wl < QUAD_PITCH) {
+      if (!masked) {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+          lds_u2v e;
+          typedef short s2v __attribute__((ext_vector_type(2)));
+          e.x = __builtin_bit_cast(unsigned, s2v{v[g][0], v[g][1]});
+          e.y = __builtin_bit_cast(unsigned, s2v{v[g][2], v[g][3]});
+          *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+          unsigned u[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            u[k] = (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u)) ? 0u : (unsigned)(unsigned short)v[g][k];
+          lds_u2v e;
+          e.x = u[0] | (u[1] << 16);
+          e.y = u[2] | (u[3] << 16);
+          *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
+        }
+      }
+    }
+    __syncthreads();
+    const int tl = fresh_lane();
+    const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
+    if (W - x0 <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true>(acc, ltaps, w.t0, w.n, lane_addr);
+    else tap_loop_quad<ACC == DIB_ACC_FMA16, false>(acc, ltaps, w.t0, w.n, lane_addr);
+  }
+  // ---- store: a store instruction writes 32 columns of row y (lanes 0-31) and of row y + 4 (lanes 32-63); lanes
+  // outside the image get an out-of-range buffer offset and are dropped by the range check ----------------------------
+  {
+    const __amdgpu_buffer_rsrc_t out_rsrc = plane_rsrc(d.out, ch, H, W);
+    const int sl = fresh_lane();
+    const int yl = y0 + wave * 8 + (sl >> 5) * 4, xl = x0 + (sl & 31);
+    const unsigned base = (unsigned)(yl * w2 + xl * 2), oob = 0x7ffffff0u;
+    if (x0 + QTILE_W <= W && y0 + TH <= H) {
+      // tile inside the image (5 of 6 at 800 x 1333): one address register, the row in the scalar offset, the column
+      // block in the immediate offset, the high halves stored straight from the registers -- no vector instruction at all
+      // (the general form below costs ~45 per wave).  Written out: there is no builtin for the d16_hi stores.
+      typedef int i4v __attribute__((ext_vector_type(4)));
+      const unsigned long long pa2 = (unsigned long long)d.out + (unsigned long long)ch * H * W * 2ull;   // as plane_rsrc
+      const i4v rs = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa2), __builtin_amdgcn_readfirstlane((int)(unsigned)(pa2 >> 32)) & 0xffff,
+                      H * W * 2, 0x00020000};
+      int so = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        asm volatile("buffer_store_short %0, %2, %3, %4 offen\n\t"
+                     "buffer_store_short_d16_hi %0, %2, %3, %4 offen offset:64\n\t"
+                     "buffer_store_short %1, %2, %3, %4 offen offset:128\n\t"
+                     "buffer_store_short_d16_hi %1, %2, %3, %4 offen offset:192"
+                     :: "v"(acc[2 * i]), "v"(acc[2 * i + 1]), "v"(base), "s"(rs), "s"(so) : "memory");
+        so += w2;
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool row_ok = yl + i < H;
+      const unsigned a0 = __builtin_bit_cast(unsigned, acc[2 * i]), a1 = __builtin_bit_cast(unsigned, acc[2 * i + 1]);
+      const unsigned ro = base + (unsigned)(i * w2);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a0 & 0xffffu), out_rsrc, row_ok && xl < W ? ro : oob, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a0 >> 16), out_rsrc, row_ok && xl + 32 < W ? ro + 64u : oob, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a1 & 0xffffu), out_rsrc, row_ok && xl + 64 < W ? ro + 128u : oob, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b16((short)(a1 >> 16), out_rsrc, row_ok && xl + 96 < W ? ro + 192u : oob, 0, 0);
+    }
+  }
+}
+
+#ifdef DIB_TIMELINE
+// scratch/timeline.py: per-workgroup residency (100 MHz wall clock) + where it ran; never defined in the product build.
+// The begin stamp and the record index wait in 16 extra bytes of LDS and the buffer pointer is a device global read (volatile) at the end, so
+// that no value stays live across the tile function: a few more live SGPRs push the allocation from 80 to 96 (+16 for the trap
+// handler's) and cost a wave per SIMD, and the measurement would not be of the shipped kernel.
+__device__ unsigned long long *g_timeline;
+#define DIB_TL_SLOT (*(unsigned long long *volatile *)&g_timeline)
+constexpr int TL_WORD = (QLDS_BYTES > NLDS_BYTES ? QLDS_BYTES : NLDS_BYTES) / 4;
+#else
+#endif
+
+// KC: the PSF canvas (128 or 256) as a compile-time constant -- table offsets, pads and the padding mode fold, ~50 scalar
+// instructions of every workgroup's prologue.  An instruction on a workgroup's serial path costs launch time out of
+// proportion (8 waves per SIMD: ~10 cycles per instruction and wave, times 3.2 rounds of workgroups).
+template <int ACC, bool QUAD, int KC>
+__global__ __launch_bounds__(256, 8) void blur_narrow_f16_kernel(BlurBatch batch) {
+  constexpr int K = KC;
+  extern __shared__ unsigned nlds[];
+#ifdef DIB_TIMELINE
+  if (threadIdx.x == 0) {   // 16 more bytes of LDS
+    *(unsigned long long *)(nlds + TL_WORD) = __builtin_amdgcn_s_memrealtime();
+    nlds[TL_WORD + 2] = blockIdx.y * 1024 + blockIdx.x;   // x extent of the BASELINE launch: 832
+  }
+#endif
+  // Prologue = two scalar round trips.  First: the whole descriptor, K and the table base, requested together (left to
+  // hipcc the fields are fetched one use at a time, a wait in front of each: six dependent round trips per workgroup).
+  const ImageDesc d = batch.img[blockIdx.y];
+  asm volatile("" ::"s"(d.in), "s"(d.out), "s"(d.C), "s"(d.H), "s"(d.W), "s"(d.table), "s"(d.tiles_x), "s"(d.tiles_y),
+               "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab));
+  const int per_ch = d.tiles_x * d.tiles_y;
+  int local;
+  if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
+  const int ch = magic_div(local, d.inv_per_ch);
+  local -= ch * per_ch;
+  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
+  if constexpr (QUAD) blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds);
+  else blur_narrow_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds);
+#ifdef DIB_TIMELINE
+  if (threadIdx.x == 0) {
+    unsigned long long *tl = DIB_TL_SLOT;
+    if (tl) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long *o = tl + 4 * (size_t)*(volatile unsigned *)(nlds + TL_WORD + 2);
+      o[0] = *(volatile unsigned long long *)(nlds + TL_WORD);
+      o[1] = __builtin_amdgcn_s_memrealtime();
+      o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+  }
+#endif
+}
+
+template <int ACC>
+__global__ __launch_bounds__(64 * NW, NW) void blur_tiled_f16_kernel(BlurBatch batch, const int *__restrict__ tables, int K,
+                                                                     unsigned long long *dbg) {
+  extern __shared__ uint2 lds[];
+  const ImageDesc &d = batch.img[blockIdx.y];
+  const int per_ch = d.tiles_x * d.tiles_y;
+  int local;
+  if (batch.xcd_bands) {
+    if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
+  } else {
+    local = blockIdx.x;              // flat order (the traffic experiment): tile index = block index
+    if (local >= d.C * per_ch) return;
+  }
+  const int ch = magic_div(local, d.inv_per_ch);
+  local -= ch * per_ch;
+  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
+  blur_tile_f16<ACC>(d, tables + (size_t)d.table * table_words(K), K, ch, tx, ty, lds, dbg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel: any K, any extent, fp16 or fp32, straight from global memory.  One thread per
+// output element.  Used for fp32 images, for 256-wide PSFs whose column extent exceeds 128, and
+// as an independent second implementation in the parity tests.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Arith;
+template <> struct Arith<__half> {
+  using V = _Float16;
+  static __device__ V weight(unsigned bits) { return __builtin_bit_cast(_Float16, (unsigned short)(bits & 0xffff)); }
+};
+template <> struct Arith<float> {
+  using V = float;
+  static __device__ V weight(unsigned bits) { return __uint_as_float(bits); }
+};
+
+template <typename T, int ACC>
+__global__ __launch_bounds__(256) void blur_generic_kernel(BlurBatch batch, const int *__restrict__ tables, int K) {
+#pragma clang fp contract(off)
+  using V = typename Arith<T>::V;
+  int b = blockIdx.x, i = 0;
+  while (i + 1 < batch.n && b >= batch.img[i + 1].tile_begin) ++i;
+  const ImageDesc &d = batch.img[i];
+  const int *tab = tables + (size_t)d.table * table_words(K);
+  const int H = d.H, W = d.W, pb = K / 2 - 1, pa = K / 2, mode = pad_mode_for(K, H, W);
+  const long long n = (long long)d.C * H * W;
+  const long long e = (long long)(b - d.tile_begin) * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int x = (int)(e % W), y = (int)((e / W) % H), ch = (int)(e / ((long long)W * H));
+  const V *src = reinterpret_cast<const V *>(d.in) + (size_t)ch * H * W;
+  const int ntaps = tab[HDR_NTAPS];
+  const uint2 *taps = reinterpret_cast<const uint2 *>(tab + table_taps_off(K));
+  V acc = 0;
+  float acc32 = 0.f;  // DIB_ACC_FP32 (fp16 images): exact products, fp32 running sum, one final rounding
+  for (int t = 0; t < ntaps; ++t) {
+    const uint2 tap = taps[t];
+    const int r = tap.x >> 8, c = tap.x & 255;
+    bool zr, zc;
+    const int sy = map_coord(y + pb - r, H, pa, pb, mode, zr);
+    const int sx = map_coord(x + pb - c, W, pa, pb, mode, zc);
+    V p = (zr || zc) ? V(0) : src[(size_t)sy * W + sx];
+    if constexpr (ACC == DIB_ACC_FP32) {
+      acc32 = acc32 + (float)p * (float)Arith<T>::weight(tap.y);
+    } else if constexpr (ACC == DIB_ACC_FMA16) {
+      acc = __builtin_fmaf16(p, Arith<T>::weight(tap.y), acc);   // native fp16 fma: one rounding
+    } else {
+      V prod = p * Arith<T>::weight(tap.y);
+      acc = acc + prod;
+    }
+  }
+  reinterpret_cast<V *>(d.out)[e] = ACC == DIB_ACC_FP32 ? (V)acc32 : acc;
+}
+
+}  // namespace dib
+
+using namespace dib;
+
+// Diagnostics only: when set, the tiled kernel records per-workgroup phase stamps (8 x u64 each).
+static unsigned long long *g_stamp_buffer = nullptr;
+extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) {
+  g_stamp_buffer = (unsigned long long *)dev_ptr;
+#ifdef DIB_TIMELINE
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(dib::g_timeline), &g_stamp_buffer, sizeof(g_stamp_buffer));
+#endif
+}
+#ifdef DIB_TIMELINE
+#define TL_EXTRA 16
+#else
+#define TL_EXTRA 0
+#endif
+// Tile order of the tiled kernel: 1 = per-XCD bands (default), 0 = flat (the traffic experiment of DESIGN.md section 4).
+static int g_xcd_bands = 1;
+// Tile shape serving fp16 images in the bit-exact and FMA16 modes (all shapes bit-identical; tests/test_blur_gpu.py
+// compares them): 0 = 128 x 32 "quad" tiles (8-byte LDS elements), 8 workgroups per CU (default), 1 = 256 x 32 tiles,
+// 4 per CU (also what DIB_ACC_FP32 runs on), 2 = 128 x 32 "narrow" tiles (4-byte LDS words; round 2's first default).
+static int shape_from_env() {   // DIB_BLUR_SHAPE=0|1|2 runs a whole test suite on one shape
+  const char *e = getenv("DIB_BLUR_SHAPE");
+  return e && e[0] >= '0' && e[0] <= '2' && !e[1] ? e[0] - '0' : 0;
+}
+static int g_shape = shape_from_env();
+extern "C" void dib_debug_set_shape(int shape) { g_shape = shape >= 0 && shape <= 2 ? shape : 0; }
+extern "C" void dib_debug_set_tile_order(int xcd_bands) { g_xcd_bands = xcd_bands ? 1 : 0; }
+
+namespace {
+// Per-device launch state: the dynamic-LDS opt-in is a per-device function attribute.  Guarded by a mutex: entry
+// points may be called from several host threads.
+struct DeviceState { bool ready = false; };
+std::mutex g_dev_mutex;
+DeviceState g_dev[64];
+
+template <typename Kern> hipError_t opt_in(Kern k, int bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+int prepare_device() {
+  int dev = 0;
+  DIB_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) { set_error("dib_sparse_blur: device index %d out of range", dev); return DIB_EINVAL; }
+  std::lock_guard<std::mutex> lock(g_dev_mutex);
+  DeviceState &st = g_dev[dev];
+  if (!st.ready) {
+    DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_BITEXACT>, LDS_BYTES));
+    DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FP32>, LDS_BYTES));
+    DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FMA16>, LDS_BYTES));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false, 128>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, false, 128>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true, 128>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, true, 128>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false, 256>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, false, 256>), NLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true, 256>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, true, 256>), QLDS_BYTES + TL_EXTRA));
+    st.ready = true;
+  }
+  return DIB_OK;
+}
+}  // namespace
+
+extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, const int *C, const int *H,
+                               const int *W, const int *table_index, int B, int dtype, void *tables_dev,
+                               int num_tables, int K, int acc_mode, void *stream) {
+  if (B < 0 || (B > 0 && (!in_dev || !out_dev || !C || !H || !W || !table_index || !tables_dev))) {
+    set_error("dib_sparse_blur: null pointer or negative batch");
+    return DIB_EINVAL;
+  }
+  if (K != 128 && K != 256) { set_error("dib_sparse_blur: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
+  if (dtype != DIB_F16 && dtype != DIB_F32) { set_error("dib_sparse_blur: unknown dtype %d", dtype); return DIB_EINVAL; }
+  if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FP32 && acc_mode != DIB_ACC_FMA16) { set_error("dib_sparse_blur: unknown accumulation mode %d", acc_mode); return DIB_EINVAL; }
+  if (acc_mode != DIB_ACC_BITEXACT && dtype != DIB_F16) { set_error("dib_sparse_blur: DIB_ACC_FP32 / DIB_ACC_FMA16 apply to fp16 images only (fp32 images already accumulate in fp32)"); return DIB_EINVAL; }
+  for (int i = 0; i < B; ++i) {
+    if (table_index[i] < 0) continue;
+    if (!in_dev[i] || !out_dev[i] || C[i] <= 0 || H[i] <= 0 || W[i] <= 0) {
+      set_error("dib_sparse_blur: image %d has a null pointer or empty shape", i);
+      return DIB_EINVAL;
+    }
+    if (in_dev[i] == out_dev[i]) { set_error("dib_sparse_blur: image %d: out aliases in", i); return DIB_EINVAL; }
+    {   // the tile index split (magic_div) is exact while channels x tiles-per-channel^2 < 2^32: ~150 Mpixel per channel
+      const unsigned long long per_ch = (unsigned long long)((W[i] + 127) / 128) * ((H[i] + 31) / 32);
+      if ((unsigned long long)C[i] * per_ch * per_ch >= 0x100000000ull) {
+        set_error("dib_sparse_blur: image %d (%d x %d x %d) is too large", i, C[i], H[i], W[i]);
+        return DIB_ESHAPE;
+      }
+    }
+    // F.pad(mode='reflect') raises unless pad < dim (blur_functions.py:59 with pads 63/64)
+    if (K == 128 && !(H[i] < 64 || W[i] < 64) && (H[i] == 64 || W[i] == 64)) {
+      set_error("Padding size should be less than the corresponding input dimension (image %d is %dx%d)", i, H[i], W[i]);
+      return DIB_ESHAPE;
+    }
+  }
+  if (num_tables <= 0) { set_error("dib_sparse_blur: num_tables must be positive"); return DIB_EINVAL; }
+  for (int i = 0; i < B; ++i)
+    if (table_index[i] >= num_tables) { set_error("dib_sparse_blur: table_index[%d] = %d out of range", i, table_index[i]); return DIB_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = prepare_device()) return rc;
+  int i = 0;
+  while (i < B) {
+    BlurBatch tiled, generic;
+    const bool narrow = g_shape != 1 && dtype == DIB_F16 && acc_mode != DIB_ACC_FP32;   // either 128-wide shape
+    const bool quad = narrow && g_shape == 0;
+    tiled.n = generic.n = 0;
+    int tiles = 0, gblocks = 0;
+    for (; i < B && tiled.n < MAX_BATCH; ++i) {
+      if (table_index[i] < 0) continue;
+      ImageDesc d;
+      d.in = in_dev[i]; d.out = out_dev[i]; d.C = C[i]; d.H = H[i]; d.W = W[i]; d.table = table_index[i];
+      d.tiles_x = narrow ? (W[i] + NTILE_W - 1) / NTILE_W : (W[i] + TILE_W - 1) / TILE_W;
+      d.tiles_y = (H[i] + TH - 1) / TH;
+      d.inv_per_ch = magic_inverse((unsigned)(d.tiles_x * d.tiles_y));
+      d.inv_tiles_x = magic_inverse((unsigned)d.tiles_x);
+      d.tab = (const int *)tables_dev + (size_t)table_index[i] * table_words(K);
+      d.tile_begin = tiles;
+      tiled.tile_begin[tiled.n] = tiles;
+      tiles += d.C * d.tiles_x * d.tiles_y;
+      tiled.img[tiled.n++] = d;
+      long long n = (long long)C[i] * H[i] * W[i];
+      d.tile_begin = gblocks;
+      gblocks += (int)((n + 255) / 256);
+      generic.img[generic.n++] = d;
+    }
+    if (tiled.n == 0) break;
+    tiled.total_tiles = tiles;
+    generic.total_tiles = gblocks;
+    tiled.xcd_bands = g_xcd_bands;
+    generic.xcd_bands = 0;
+    if (dtype == DIB_F16) {
+      for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
+      // x extent: the longest image of the launch -- 8 x its longest band, or (flat order) its tile count
+      int gx = 0;
+      for (int k = 0; k < tiled.n; ++k) {
+        const int T = tiled.tile_begin[k + 1] - tiled.tile_begin[k];
+        int ext = T;
+        if (g_xcd_bands || narrow) {
+          int longest = 0;
+          for (int x = 0; x < 8; ++x) {
+            const int len = (((x + 1) * T) >> 3) - ((x * T) >> 3);
+            longest = len > longest ? len : longest;
+          }
+          ext = 8 * longest;
+        }
+        gx = ext > gx ? ext : gx;
+      }
+      const dim3 grid(gx, tiled.n);
+#define DIB_LAUNCH_128(ACCM, Q, LDSB)                                                                                       \
+  do {                                                                                                                     \
+    if (K == 128) hipLaunchKernelGGL((blur_narrow_f16_kernel<ACCM, Q, 128>), grid, dim3(256), (LDSB) + TL_EXTRA, s, tiled); \
+    else hipLaunchKernelGGL((blur_narrow_f16_kernel<ACCM, Q, 256>), grid, dim3(256), (LDSB) + TL_EXTRA, s, tiled);          \
+  } while (0)
+      if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_128(DIB_ACC_FMA16, true, QLDS_BYTES);
+      else if (quad) DIB_LAUNCH_128(DIB_ACC_BITEXACT, true, QLDS_BYTES);
+      else if (narrow && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_128(DIB_ACC_FMA16, false, NLDS_BYTES);
+      else if (narrow) DIB_LAUNCH_128(DIB_ACC_BITEXACT, false, NLDS_BYTES);
+#undef DIB_LAUNCH_128
+      else if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FP32>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FMA16>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+      else hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
+    } else {
+      hipLaunchKernelGGL((blur_generic_kernel<float, DIB_ACC_BITEXACT>), dim3(gblocks), dim3(256), 0, s, generic, (const int *)tables_dev, K);
+    }
+    DIB_HIP_CHECK(hipGetLastError());
+  }
+  return DIB_OK;
+}
+
+// Test hook (not part of the drop-in boundary): runs the generic kernel on fp16 images so the
+// parity tests can compare two independent device implementations.
+extern "C" int dib_sparse_blur_generic(const void *in_dev, void *out_dev, int C, int H, int W, int dtype,
+                                       const void *table_dev, int K, void *stream) {
+  if (!in_dev || !out_dev || !table_dev) { set_error("dib_sparse_blur_generic: null pointer"); return DIB_EINVAL; }
+  BlurBatch g;
+  g.n = 1;
+  ImageDesc d;
+  d.in = in_dev; d.out = out_dev; d.C = C; d.H = H; d.W = W; d.table = 0; d.tile_begin = 0; d.tiles_x = d.tiles_y = 0; d.inv_per_ch = d.inv_tiles_x = 0; d.tab = (const int *)table_dev;
+  g.img[0] = d;
+  int blocks = (int)(((long long)C * H * W + 255) / 256);
+  g.total_tiles = blocks;
+  g.xcd_bands = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DIB_F16)
+    hipLaunchKernelGGL((blur_generic_kernel<__half, DIB_ACC_BITEXACT>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
+  else if (dtype == DIB_F32)
+    hipLaunchKernelGGL((blur_generic_kernel<float, DIB_ACC_BITEXACT>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
+  else if (dtype == 2)  // fp16 image, DIB_ACC_FP32 arithmetic
+    hipLaunchKernelGGL((blur_generic_kernel<__half, DIB_ACC_FP32>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
+  else  // dtype 3: fp16 image, DIB_ACC_FMA16 arithmetic
+    hipLaunchKernelGGL((blur_generic_kernel<__half, DIB_ACC_FMA16>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
