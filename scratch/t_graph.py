@@ -40,3 +40,29 @@ for nstreams in (1, 2, 3):
     t = timeit(g.replay, 200) / G
     print("graph of %d steps on %d stream(s): %.2f us per step, outputs identical: %s" % (G, nstreams, t, ok))
     del g, keep
+
+# Variant: every step's tap compaction on its own captured stream C (they only depend on the resident PSFs), the blurs
+# alternating between streams A and B and waiting for their tables' event -- the way engine.py runs the two (compaction on
+# a side stream behind the PSF upload).
+for nblur in (1, 2, 3):
+    sc = torch.cuda.Stream(); sb = [torch.cuda.Stream() for _ in range(nblur)]
+    g = torch.cuda.CUDAGraph(); keep = []
+    with torch.cuda.graph(g, stream=sb[0], capture_error_mode="thread_local"):
+        fork = torch.cuda.Event(); fork.record(sb[0])
+        for s in [sc] + sb[1:]: s.wait_event(fork)
+        for i in range(G):
+            with torch.cuda.stream(sc):
+                tabs = blur_ops.compact_psfs(psfs, normalize=True)
+                tabs.ready = torch.cuda.Event(); tabs.ready.record(sc)
+            with torch.cuda.stream(sb[i % nblur]):
+                batch = list(images)
+                BF.blur_image_list(batch, dicts, psfs, tables=tabs)
+                keep.append((batch, tabs))
+        for s in [sc] + sb[1:]:
+            j = torch.cuda.Event(); j.record(s); sb[0].wait_event(j)
+    for _ in range(20): g.replay()
+    torch.cuda.synchronize()
+    ok = all(torch.equal(a, b) for out, _ in keep for a, b in zip(out, ref))
+    t = timeit(g.replay, 200) / G
+    print("graph of %d steps, compaction stream + %d blur stream(s): %.2f us per step, outputs identical: %s" % (G, nblur, t, ok))
+    del g, keep
