@@ -464,180 +464,15 @@ __device__ __forceinline__ bool band_entry(int T, int x, int t, int &local) {
   return t < hi - lo;
 }
 
-// =============================================================================================================
-// Narrow shape: 128 x 32 tiles.  Lane l owns columns x0 + l and x0 + l + 64 (ONE packed register per row), the LDS
-// word is 4 bytes {P[j], P[j+64]} and the window 48 rows x 96 words x 4 B = 18 KB: seven workgroups per CU instead of
-// four.  The kernel is a closed system -- a CU's slots each run dispatch -> prologue -> fill -> taps -> store in
-// sequence, and its time is (tiles per slot) x (latency of one workgroup) -- so slots are what buys throughput:
-// measured on the BASELINE batch 3 / 4 slots gave 61 / 51 us with the 256-wide tile.  Costs: 1.25 x instead of
-// 1.125 x halo columns, and twice the workgroups (their fixed cost is ~2.4 us each).
-// =============================================================================================================
-constexpr int NTILE_W = 128;
-constexpr int NPITCH = WIN_PITCH * 4;         // bytes per LDS row (384)
-constexpr int NLDS_BYTES = LROWS * NPITCH;    // 18,432 B
-static_assert(NPITCH == 384, "the asm below hard-codes the LDS row pitch");
-
-// The r8 tap loop on 4-byte words: the ltap word carries the byte offset of the 8-byte-word layout, so it is halved
-// (s_bfe_u32: bits 15..1) -- one more scalar instruction per tap.  Buffers v[32:39] / v[40:47], address v48.
-// Operands: %0-%7 accumulators, %8 byte offset of the next ltap, %9 taps left, %10 A, %11 B, %12 C, %13 temp, %14 ltaps, %15 lane base.
-#define DIBN_MUL(b) "v_pk_mul_f16 v" #b ", %10, v" #b " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
-#define DIBN_ADD(b, i) "v_pk_add_f16 %" #i ", %" #i ", v" #b "\n\t"
-#define DIBN_FMA(b, i) "v_pk_fma_f16 %" #i ", %10, v" #b ", %" #i " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-#define DIBN_MADD_A DIBN_MUL(32) DIBN_MUL(33) DIBN_MUL(34) DIBN_MUL(35) DIBN_MUL(36) DIBN_MUL(37) DIBN_MUL(38) DIBN_MUL(39) \
-  DIBN_ADD(32, 0) DIBN_ADD(33, 1) DIBN_ADD(34, 2) DIBN_ADD(35, 3) DIBN_ADD(36, 4) DIBN_ADD(37, 5) DIBN_ADD(38, 6) DIBN_ADD(39, 7)
-#define DIBN_MADD_B DIBN_MUL(40) DIBN_MUL(41) DIBN_MUL(42) DIBN_MUL(43) DIBN_MUL(44) DIBN_MUL(45) DIBN_MUL(46) DIBN_MUL(47) \
-  DIBN_ADD(40, 0) DIBN_ADD(41, 1) DIBN_ADD(42, 2) DIBN_ADD(43, 3) DIBN_ADD(44, 4) DIBN_ADD(45, 5) DIBN_ADD(46, 6) DIBN_ADD(47, 7)
-#define DIBN_FMADD_A DIBN_FMA(32, 0) DIBN_FMA(33, 1) DIBN_FMA(34, 2) DIBN_FMA(35, 3) DIBN_FMA(36, 4) DIBN_FMA(37, 5) DIBN_FMA(38, 6) DIBN_FMA(39, 7)
-#define DIBN_FMADD_B DIBN_FMA(40, 0) DIBN_FMA(41, 1) DIBN_FMA(42, 2) DIBN_FMA(43, 3) DIBN_FMA(44, 4) DIBN_FMA(45, 5) DIBN_FMA(46, 6) DIBN_FMA(47, 7)
-#define DIBN_READ(base)                                                                                      \
-  "s_bfe_u32 %13, %11, 0xf0001\n\tv_add_u32 v48, %13, %15\n\t"                                                \
-  "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+1], v48 offset:384\n\t"                           \
-  "ds_read_b32 v[" #base "+2], v48 offset:768\n\tds_read_b32 v[" #base "+3], v48 offset:1152\n\t"             \
-  "ds_read_b32 v[" #base "+4], v48 offset:1536\n\tds_read_b32 v[" #base "+5], v48 offset:1920\n\t"            \
-  "ds_read_b32 v[" #base "+6], v48 offset:2304\n\tds_read_b32 v[" #base "+7], v48 offset:2688\n\t"
-#define DIBN_NEXTTAP "s_load_dword %12, %14, %8\n\ts_add_u32 %8, %8, 4\n\t"
-template <bool FUSED>
-__device__ __forceinline__ void tap_loop_narrow(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
-  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
-  unsigned sA, sB, sC, st;
-  unsigned a[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
-#define DIB_RN_ASM(ARITH_A, ARITH_B) \
-  asm volatile( \
-      "s_load_dword %11, %14, %8\n\ts_add_u32 %8, %8, 4\n\t" DIBN_NEXTTAP \
-      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" DIBN_READ(32) \
-      "Ldibn_loop%=:\n\t" \
-      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
-      DIBN_READ(40) DIBN_NEXTTAP \
-      ARITH_A \
-      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 Ldibn_done%=\n\t" \
-      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %10, %11\n\ts_mov_b32 %11, %12\n\t" \
-      DIBN_READ(32) DIBN_NEXTTAP \
-      ARITH_B \
-      "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc0 Ldibn_loop%=\n\t" \
-      "Ldibn_done%=:\n\t" \
-      "s_waitcnt lgkmcnt(0)" \
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+s"(toff), "+s"(cnt), \
-        "=&s"(sA), "=&s"(sB), "=&s"(sC), "=&s"(st) \
-      : "s"(ltaps), "v"(lane_addr) \
-      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "scc", \
-        "memory")
-  if constexpr (FUSED) { DIB_RN_ASM(DIBN_FMADD_A, DIBN_FMADD_B); } else { DIB_RN_ASM(DIBN_MADD_A, DIBN_MADD_B); }
-#undef DIB_RN_ASM
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
-}
-
-template <int ACC>
-__device__ __forceinline__ void blur_narrow_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
-                                                     unsigned *lds) {
-#pragma clang fp contract(off)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = d.H, W = d.W, w2 = W * 2;
-  const int mode = pad_mode_for(K, H, W);
-  const int pb = K / 2 - 1, pa = K / 2;
-  const int nsegs = tab[HDR_NSEGS];
-  const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
-  const unsigned long long la = (unsigned long long)(tab + table_ltaps_off(K));
-  const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
-                                   (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
-  const int x0 = tx * NTILE_W, y0 = ty * TH;
-  const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(d.in, ch, H, W);
-  h2 acc[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) acc[i] = h2{0, 0};
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
-  const unsigned lane_addr = lds0 + (unsigned)((wave * R) * NPITCH + lane * 4);
-  const int qb = wave * G;
-  const unsigned wp = lds0 + (unsigned)(qb * NPITCH + lane * 4);
-  typedef __attribute__((address_space(3))) unsigned lds_u1;
-
-  for (int sg = 0; sg < nsegs; ++sg) {
-    const Window w = window_of(segs[sg]);
-    // ---- fill: per LDS row the three values P[lane + 64k] ---------------------------------------------------------
-    unsigned v[G][3], coff[3];
-    int soff[G];
-    unsigned zmask = 0;
-    const int c_first = x0 + pb - w.cmax, r_first = y0 + pb - w.rl;
-    const bool zero_mode = mode == PAD_ZERO;
-    if (!zero_mode && c_first >= 0 && c_first + 63 + 128 <= W - 1) {
-      const unsigned c0 = 2u * (unsigned)(c_first + lane);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) coff[k] = c0 + 128u * k;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        bool z;
-        coff[k] = 2u * (unsigned)map_coord_sel(c_first + lane + 64 * k, W, pa, pb, mode, z);
-        zmask |= z ? 1u << k : 0u;
-      }
-    }
-    if (!zero_mode && r_first >= 0 && r_first + LROWS - 1 <= H - 1) {
-      const int s0 = (r_first + qb) * w2;
-#pragma unroll
-      for (int g = 0; g < G; ++g) soff[g] = s0 + g * w2;
-    } else {
-      const int nrows = TH + (w.rl - w.rf);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        bool zr;
-        const int sr = map_coord_sel(r_first + min(qb + g, nrows - 1), H, pa, pb, mode, zr);
-        zmask |= zr ? 1u << (8 + g) : 0u;
-        soff[g] = sr * w2;
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int so = __builtin_amdgcn_readfirstlane(soff[g]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) v[g][k] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
-    }
-    if (sg > 0) __syncthreads();  // every wave is done reading the previous window
-    const bool second = lane < w.cmax - w.cmin;
-    const bool masked = __builtin_amdgcn_ballot_w64(zmask != 0) != 0;   // PAD_ZERO images only
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (masked) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u)) v[g][k] = 0;
-      }
-      const unsigned w0 = v[g][0] | (v[g][1] << 16);
-      *(lds_u1 *)(size_t)(wp + (unsigned)(g * NPITCH)) = w0;
-      if (second) *(lds_u1 *)(size_t)(wp + (unsigned)(g * NPITCH + 256)) = __builtin_amdgcn_alignbit(v[g][2], w0, 16);
-    }
-    __syncthreads();
-    tap_loop_narrow<ACC == DIB_ACC_FMA16>(acc, ltaps, w.t0, w.n, lane_addr);
-  }
-  // ---- store (see store_tile: out-of-range lanes get an out-of-range offset, rows below the image a null descriptor) ----
-  {
-    const unsigned long long pa2 = (unsigned long long)d.out + (unsigned long long)ch * H * W * 2ull;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pa2), hi = __builtin_amdgcn_readfirstlane((unsigned)(pa2 >> 32));
-    void *plane = (void *)(((unsigned long long)hi << 32) | lo);
-    const int xr = W - x0 - lane;
-    const unsigned voff = 2u * (unsigned)(x0 + lane), oob = 0x7ffffff0u;
-    const unsigned vo0 = xr > 0 ? voff : oob, vo1 = xr > 64 ? voff + 128u : oob;
-    const int yb = y0 + wave * R;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(plane, 0, yb + i < H ? H * w2 : 0, 0x00020000);
-      const int so = (yb + i) * w2;
-      const unsigned a = __builtin_bit_cast(unsigned, acc[i]);
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a & 0xffffu), out_rsrc, vo0, so, 0);
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a >> 16), out_rsrc, vo1, so, 0);
-    }
-  }
-}
-
 // =============================================================================================
-// "Quad" shape: 128-wide tiles like the narrow shape, but a lane owns FOUR columns of FOUR rows --
-// lane = 32 h + j computes columns {j, j+32, j+64, j+96} of rows 4h .. 4h+3 of its wave's 8 rows -- and the
-// window is stored as 8-byte elements  e[k] = {P[k], P[k+32] | P[k+64], P[k+96]}  (k = 0 .. 31 + SEG_COLS),
-// so that one tap is 4 x ds_read_b64 per lane instead of 8 x ds_read_b32: the LDS serves 256 B per clock for
-// 8-byte reads and 128 B for 4-byte ones (MI355X_MICROARCH.md, LDS table), and the narrow shape's tap phase ran at
-// the LDS's rate, not the vector ALU's (16 LDS cycles against ~42 ALU cycles per wave-tap, four SIMDs sharing one LDS).
+// Default ("quad") shape: 128 x 32 tiles, 4 waves, eight workgroups per CU (the kernel is a closed system: a CU's slots
+// each run dispatch -> prologue -> fill -> taps -> store in sequence, so slots are what buys throughput: 3 / 4 / 8 slots
+// gave 61 / 51 / 46 us on the BASELINE batch).  A lane owns FOUR columns of FOUR rows -- lane = 32 h + j computes
+// columns {j, j+32, j+64, j+96} of rows 4h .. 4h+3 of its wave's 8 rows -- and the window is stored as 8-byte elements
+// e[k] = {P[k], P[k+32] | P[k+64], P[k+96]}  (k = 0 .. 31 + SEG_COLS), so that one tap is 4 x ds_read_b64 per lane: the
+// LDS serves 256 B per clock for 8-byte reads and 128 B for 4-byte ones (MI355X_MICROARCH.md, LDS table), and the first
+// 128-wide shape of round 2 (4-byte words {P[j], P[j+64]}, 8 x ds_read_b32 per tap; scratch/blur_narrow_shape.hip) ran
+// its tap phase at the LDS's rate, not the vector ALU's.
 // Element k + dcol is 8-byte aligned for every tap column, and the 32 lanes of an LDS lane group read 32
 // consecutive elements = all 64 banks once.  44 rows x 56 elements x 8 B = 19,712 B: eight workgroups per CU.
 // =============================================================================================
@@ -649,7 +484,7 @@ static_assert(LROWS % NW == 0, "every wave fills the same number of window rows"
 
 // Tap loop of the quad shape: 4 x 8-byte reads per tap, rows i = 0..3 land in v[base+2i : base+2i+1] = the operands of
 // accumulators 2i (columns j, j+32) and 2i+1 (columns j+64, j+96); the LDS address is one v_mad_u32_u16 (low 16 bits of
-// the ltap word + lane base).  Same arithmetic and the same one-tap LDS look-ahead as tap_loop_narrow; the scalar side
+// the ltap word + lane base).  Same arithmetic and the same one-tap LDS look-ahead as the 256-wide shape's loop; the scalar side
 // is leaner because every instruction a wave issues costs launch time here (measured by padding the loop: +0.24 us per
 // million scalar, +0.69 per million vector, +1.25 per million LDS instructions): the ltap words
 // arrive two at a time (s_load_dwordx2) into three fixed register pairs P = s[36:37], Q = s[38:39], R = s[40:41] that the
@@ -664,12 +499,13 @@ static_assert(LROWS % NW == 0, "every wave fills the same number of window rows"
 //   tap 6k+4: load Q <- w[6k+8..9] | read Y at offset(R.hi) | multiply-add X by weight(R.lo)
 //   tap 6k+5:                        read X at offset(P.lo) | multiply-add Y by weight(R.hi)
 // Operands: %0-%7 accumulators, %8 byte offset of the next ltap pair, %9 taps left, %10 ltaps, %11 lane base.
+#define DIBQ_ADD(b, i) "v_pk_add_f16 %" #i ", %" #i ", v" #b "\n\t"
 #define DIBQ_MUL(b, W) "v_pk_mul_f16 v" #b ", " W ", v" #b " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
 #define DIBQ_FMA(b, i, W) "v_pk_fma_f16 %" #i ", " W ", v" #b ", %" #i " op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
 #define DIBQ_MADD_X(W) DIBQ_MUL(32, W) DIBQ_MUL(33, W) DIBQ_MUL(34, W) DIBQ_MUL(35, W) DIBQ_MUL(36, W) DIBQ_MUL(37, W) DIBQ_MUL(38, W) DIBQ_MUL(39, W) \
-  DIBN_ADD(32, 0) DIBN_ADD(33, 1) DIBN_ADD(34, 2) DIBN_ADD(35, 3) DIBN_ADD(36, 4) DIBN_ADD(37, 5) DIBN_ADD(38, 6) DIBN_ADD(39, 7)
+  DIBQ_ADD(32, 0) DIBQ_ADD(33, 1) DIBQ_ADD(34, 2) DIBQ_ADD(35, 3) DIBQ_ADD(36, 4) DIBQ_ADD(37, 5) DIBQ_ADD(38, 6) DIBQ_ADD(39, 7)
 #define DIBQ_MADD_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(41, W) DIBQ_MUL(42, W) DIBQ_MUL(43, W) DIBQ_MUL(44, W) DIBQ_MUL(45, W) DIBQ_MUL(46, W) DIBQ_MUL(47, W) \
-  DIBN_ADD(40, 0) DIBN_ADD(41, 1) DIBN_ADD(42, 2) DIBN_ADD(43, 3) DIBN_ADD(44, 4) DIBN_ADD(45, 5) DIBN_ADD(46, 6) DIBN_ADD(47, 7)
+  DIBQ_ADD(40, 0) DIBQ_ADD(41, 1) DIBQ_ADD(42, 2) DIBQ_ADD(43, 3) DIBQ_ADD(44, 4) DIBQ_ADD(45, 5) DIBQ_ADD(46, 6) DIBQ_ADD(47, 7)
 #define DIBQ_FMADD_X(W) DIBQ_FMA(32, 0, W) DIBQ_FMA(33, 1, W) DIBQ_FMA(34, 2, W) DIBQ_FMA(35, 3, W) DIBQ_FMA(36, 4, W) DIBQ_FMA(37, 5, W) DIBQ_FMA(38, 6, W) DIBQ_FMA(39, 7, W)
 #define DIBQ_FMADD_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(41, 1, W) DIBQ_FMA(42, 2, W) DIBQ_FMA(43, 3, W) DIBQ_FMA(44, 4, W) DIBQ_FMA(45, 5, W) DIBQ_FMA(46, 6, W) DIBQ_FMA(47, 7, W)
 #define DIBQ_READ(base, OFF)                                                                                 \
@@ -683,8 +519,8 @@ static_assert(LROWS % NW == 0, "every wave fills the same number of window rows"
   "v_mad_u32_u16 v48, " OFF ", 1, %11\n\t"                                                                    \
   "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+2], v48 offset:448\n\t"                            \
   "ds_read_b32 v[" #base "+4], v48 offset:896\n\tds_read_b32 v[" #base "+6], v48 offset:1344\n\t"
-#define DIBQ_MADDH_X(W) DIBQ_MUL(32, W) DIBQ_MUL(34, W) DIBQ_MUL(36, W) DIBQ_MUL(38, W) DIBN_ADD(32, 0) DIBN_ADD(34, 2) DIBN_ADD(36, 4) DIBN_ADD(38, 6)
-#define DIBQ_MADDH_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(42, W) DIBQ_MUL(44, W) DIBQ_MUL(46, W) DIBN_ADD(40, 0) DIBN_ADD(42, 2) DIBN_ADD(44, 4) DIBN_ADD(46, 6)
+#define DIBQ_MADDH_X(W) DIBQ_MUL(32, W) DIBQ_MUL(34, W) DIBQ_MUL(36, W) DIBQ_MUL(38, W) DIBQ_ADD(32, 0) DIBQ_ADD(34, 2) DIBQ_ADD(36, 4) DIBQ_ADD(38, 6)
+#define DIBQ_MADDH_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(42, W) DIBQ_MUL(44, W) DIBQ_MUL(46, W) DIBQ_ADD(40, 0) DIBQ_ADD(42, 2) DIBQ_ADD(44, 4) DIBQ_ADD(46, 6)
 #define DIBQ_FMADDH_X(W) DIBQ_FMA(32, 0, W) DIBQ_FMA(34, 2, W) DIBQ_FMA(36, 4, W) DIBQ_FMA(38, 6, W)
 #define DIBQ_FMADDH_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(42, 2, W) DIBQ_FMA(44, 4, W) DIBQ_FMA(46, 6, W)
 #define DIBQ_LOAD(PAIR) "s_load_dwordx2 " PAIR ", %10, %8\n\ts_add_u32 %8, %8, 8\n\t"
@@ -719,15 +555,6 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
 #undef DIB_RQ_ASM
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
-}
-
-// {lo, hi} 16-bit values -> one dword.  As asm because hipcc zero-extends a 16-bit buffer load's result with a v_and
-// before any 32-bit use (the hardware already did), even when the user is v_perm_b32, which never looks at those bits:
-// a 16-bit asm operand is passed any-extended.
-__device__ __forceinline__ unsigned pack_lo16(short hi, short lo) {
-  unsigned r;
-  asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(0x05040100u));
-  return r;
 }
 
 template <int ACC>
@@ -895,15 +722,15 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
 // handler's) and cost a wave per SIMD, and the measurement would not be of the shipped kernel.
 __device__ unsigned long long *g_timeline;
 #define DIB_TL_SLOT (*(unsigned long long *volatile *)&g_timeline)
-constexpr int TL_WORD = (QLDS_BYTES > NLDS_BYTES ? QLDS_BYTES : NLDS_BYTES) / 4;
+constexpr int TL_WORD = QLDS_BYTES / 4;
 #else
 #endif
 
 // KC: the PSF canvas (128 or 256) as a compile-time constant -- table offsets, pads and the padding mode fold, ~50 scalar
 // instructions of every workgroup's prologue.  An instruction on a workgroup's serial path costs launch time out of
 // proportion (8 waves per SIMD: ~10 cycles per instruction and wave, times 3.2 rounds of workgroups).
-template <int ACC, bool QUAD, int KC>
-__global__ __launch_bounds__(256, 8) void blur_narrow_f16_kernel(BlurBatch batch) {
+template <int ACC, int KC>
+__global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch) {
   constexpr int K = KC;
   extern __shared__ unsigned nlds[];
 #ifdef DIB_TIMELINE
@@ -923,8 +750,7 @@ __global__ __launch_bounds__(256, 8) void blur_narrow_f16_kernel(BlurBatch batch
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
   const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  if constexpr (QUAD) blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds);
-  else blur_narrow_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds);
+  blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds);
 #ifdef DIB_TIMELINE
   if (threadIdx.x == 0) {
     unsigned long long *tl = DIB_TL_SLOT;
@@ -1031,13 +857,13 @@ extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) {
 static int g_xcd_bands = 1;
 // Tile shape serving fp16 images in the bit-exact and FMA16 modes (all shapes bit-identical; tests/test_blur_gpu.py
 // compares them): 0 = 128 x 32 "quad" tiles (8-byte LDS elements), 8 workgroups per CU (default), 1 = 256 x 32 tiles,
-// 4 per CU (also what DIB_ACC_FP32 runs on), 2 = 128 x 32 "narrow" tiles (4-byte LDS words; round 2's first default).
-static int shape_from_env() {   // DIB_BLUR_SHAPE=0|1|2 runs a whole test suite on one shape
+// 4 per CU (what DIB_ACC_FP32 always runs on: the second, independent tiled implementation).
+static int shape_from_env() {   // DIB_BLUR_SHAPE=0|1 runs a whole test suite on one shape
   const char *e = getenv("DIB_BLUR_SHAPE");
-  return e && e[0] >= '0' && e[0] <= '2' && !e[1] ? e[0] - '0' : 0;
+  return e && e[0] == '1' && !e[1] ? 1 : 0;
 }
 static int g_shape = shape_from_env();
-extern "C" void dib_debug_set_shape(int shape) { g_shape = shape >= 0 && shape <= 2 ? shape : 0; }
+extern "C" void dib_debug_set_shape(int shape) { g_shape = shape == 1 ? 1 : 0; }
 extern "C" void dib_debug_set_tile_order(int xcd_bands) { g_xcd_bands = xcd_bands ? 1 : 0; }
 
 namespace {
@@ -1061,14 +887,10 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_BITEXACT>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FP32>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FMA16>, LDS_BYTES));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false, 128>), NLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, false, 128>), NLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true, 128>), QLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, true, 128>), QLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, false, 256>), NLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, false, 256>), NLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_BITEXACT, true, 256>), QLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_narrow_f16_kernel<DIB_ACC_FMA16, true, 256>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 128>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 256>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 256>), QLDS_BYTES + TL_EXTRA));
     st.ready = true;
   }
   return DIB_OK;
@@ -1114,15 +936,14 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   int i = 0;
   while (i < B) {
     BlurBatch tiled, generic;
-    const bool narrow = g_shape != 1 && dtype == DIB_F16 && acc_mode != DIB_ACC_FP32;   // either 128-wide shape
-    const bool quad = narrow && g_shape == 0;
+    const bool quad = g_shape == 0 && dtype == DIB_F16 && acc_mode != DIB_ACC_FP32;
     tiled.n = generic.n = 0;
     int tiles = 0, gblocks = 0;
     for (; i < B && tiled.n < MAX_BATCH; ++i) {
       if (table_index[i] < 0) continue;
       ImageDesc d;
       d.in = in_dev[i]; d.out = out_dev[i]; d.C = C[i]; d.H = H[i]; d.W = W[i]; d.table = table_index[i];
-      d.tiles_x = narrow ? (W[i] + NTILE_W - 1) / NTILE_W : (W[i] + TILE_W - 1) / TILE_W;
+      d.tiles_x = quad ? (W[i] + QTILE_W - 1) / QTILE_W : (W[i] + TILE_W - 1) / TILE_W;
       d.tiles_y = (H[i] + TH - 1) / TH;
       d.inv_per_ch = magic_inverse((unsigned)(d.tiles_x * d.tiles_y));
       d.inv_tiles_x = magic_inverse((unsigned)d.tiles_x);
@@ -1148,7 +969,7 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       for (int k = 0; k < tiled.n; ++k) {
         const int T = tiled.tile_begin[k + 1] - tiled.tile_begin[k];
         int ext = T;
-        if (g_xcd_bands || narrow) {
+        if (g_xcd_bands || quad) {
           int longest = 0;
           for (int x = 0; x < 8; ++x) {
             const int len = (((x + 1) * T) >> 3) - ((x * T) >> 3);
@@ -1159,16 +980,14 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
         gx = ext > gx ? ext : gx;
       }
       const dim3 grid(gx, tiled.n);
-#define DIB_LAUNCH_128(ACCM, Q, LDSB)                                                                                       \
-  do {                                                                                                                     \
-    if (K == 128) hipLaunchKernelGGL((blur_narrow_f16_kernel<ACCM, Q, 128>), grid, dim3(256), (LDSB) + TL_EXTRA, s, tiled); \
-    else hipLaunchKernelGGL((blur_narrow_f16_kernel<ACCM, Q, 256>), grid, dim3(256), (LDSB) + TL_EXTRA, s, tiled);          \
+#define DIB_LAUNCH_QUAD(ACCM)                                                                                             \
+  do {                                                                                                                   \
+    if (K == 128) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled); \
+    else hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 256>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled);          \
   } while (0)
-      if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_128(DIB_ACC_FMA16, true, QLDS_BYTES);
-      else if (quad) DIB_LAUNCH_128(DIB_ACC_BITEXACT, true, QLDS_BYTES);
-      else if (narrow && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_128(DIB_ACC_FMA16, false, NLDS_BYTES);
-      else if (narrow) DIB_LAUNCH_128(DIB_ACC_BITEXACT, false, NLDS_BYTES);
-#undef DIB_LAUNCH_128
+      if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_QUAD(DIB_ACC_FMA16);
+      else if (quad) DIB_LAUNCH_QUAD(DIB_ACC_BITEXACT);
+#undef DIB_LAUNCH_QUAD
       else if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FP32>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FMA16>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);
       else hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);

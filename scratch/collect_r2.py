@@ -8,7 +8,7 @@ def counters(sub, skip=6):
     for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
         acc = {}
         for r in csv.DictReader(open(f)):
-            if "blur_narrow" in r["Kernel_Name"]:
+            if "blur_quad" in r["Kernel_Name"]:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in acc.items():
             v = v[skip:] if len(v) > skip else v          # the first launches of the cold run still fill the cache
@@ -21,7 +21,7 @@ for sub in ("fetch_cold", "write_cold"):
     cold.update(counters(sub, 12))
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
 rows = list(csv.DictReader(open(stats)))
-blur = [r for r in rows if "blur_narrow" in r["Name"] and "<0, true, 128>" in r["Name"]][0]      # bit-exact, quad layout, 128 canvas
+blur = [r for r in rows if "blur_quad" in r["Name"] and "<0, 128>" in r["Name"]][0]      # bit-exact, 128 canvas
 comp = [r for r in rows if "psf_compact" in r["Name"]][0]
 shutil.copy(stats, os.path.join(root, "profiles", "r2_bench_kernel_stats.csv"))
 line = [l for l in open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines() if l.startswith("{")][-1]
@@ -32,7 +32,7 @@ tc = cold["FETCH_SIZE"] * 1024 * 2.0 + cold["WRITE_SIZE"] * 1024
 doc = {
     "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-train-step (kernel stats in r2_bench_kernel_stats.csv); PMC: separate rocprofv3 --pmc passes over scratch/prof_blur_r2.py (same workload; warm = one resident batch, cold = 6 input batches + 6 live output blocks round-robin, 614 MB)",
     "workload": "configs[1]: batch 8 x 3x800x1333 fp16, 8 PSFs (expl 0.005, low exposure), taps per PSF [43,53,28,26,56,51,19,26]",
-    "kernel": "dib::blur_narrow_f16_kernel<0, true, 128> (128 x 32 tiles, 'quad' window layout of 8-byte LDS elements, 8 workgroups per CU, XCD-band tile order, bit-exact mode)",
+    "kernel": "dib::blur_quad_f16_kernel<0, 128> (128 x 32 tiles, 'quad' window layout of 8-byte LDS elements, 8 workgroups per CU, XCD-band tile order, bit-exact mode)",
     "per_launch_warm": {k: warm[k] for k in sorted(warm)},
     "per_launch_cold": {k: cold[k] for k in sorted(cold)},
     "kernel_avg_ns": float(blur["AverageNs"]), "kernel_calls": int(blur["Calls"]), "compact_avg_ns": float(comp["AverageNs"]),

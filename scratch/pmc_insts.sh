@@ -1,5 +1,5 @@
 #!/bin/bash
-# Instruction counts of the blur kernel by kind (one --pmc pass each; scratch/prof_blur_r2.py warm).  DIB_BLUR_SHAPE selects the shape.
+# Instruction counts of the blur kernel by kind (one --pmc pass each; scratch/prof_blur_r2.py warm).  DIB_BLUR_SHAPE=0|1 selects the shape.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/insts_${DIB_BLUR_SHAPE:-0}; rm -rf $O; mkdir -p $O
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH -d $O/a --output-format csv -- python3 scratch/prof_blur_r2.py 8 warm > /dev/null 2>&1

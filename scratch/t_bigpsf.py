@@ -35,7 +35,7 @@ for expl in (0.005, 0.001, 0.00005):
         idx = sorted(range(8), key=lambda k: -taps[k])
         ordered = [images[k] for k in idx]
         res = []
-        for shape in ((0, 1) if os.environ.get("DIB_LIB") else (0, 1, 2)):
+        for shape in (0, 1):
             l.dib_debug_set_shape(shape)
             res.append(timeit(lambda: blur_ops.sparse_blur(list(ordered), idx, tables, 0)))
         l.dib_debug_set_shape(0)
@@ -43,5 +43,5 @@ for expl in (0.005, 0.001, 0.00005):
         if os.environ.get("DIB_LIB"):
             print("expl %-8g fraction %.2f: taps %s segments %s | old build: shape 0 %.1f us  shape 1 %.1f us" % (expl, frac, taps, nseg, res[0], res[1]), flush=True)
         else:
-            print("expl %-8g fraction %.2f: taps %s segments %s | quad %.1f us  256-wide %.1f us  4-byte 128-wide %.1f us | quad fma16 %.1f us" % (
-                expl, frac, taps, nseg, res[0], res[1], res[2], fma), flush=True)
+            print("expl %-8g fraction %.2f: taps %s segments %s | quad %.1f us  256-wide %.1f us | quad fma16 %.1f us" % (
+                expl, frac, taps, nseg, res[0], res[1], fma), flush=True)

@@ -1,5 +1,5 @@
 """A/B of the tiled blur's tile shapes inside ONE process (boxes differ by several per cent):
-0 = 128 x 32 "quad" tiles (8-byte LDS elements, default), 1 = 256 x 32 tiles, 2 = 128 x 32 "narrow" tiles (4-byte LDS words)."""
+0 = 128 x 32 "quad" tiles (8-byte LDS elements, default), 1 = 256 x 32 tiles."""
 import sys, ctypes
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -22,7 +22,7 @@ ring = [None] * 6
 def cold(k, mode):
     j = k % 6; ring[j] = None; ring[j] = blur_ops.sparse_blur(list(sets[j]), idx, tables, mode)
 for rep in range(3):
-    for shape in (1, 2, 0):
+    for shape in (1, 0):
         l.dib_debug_set_shape(shape)
         w0 = timeit(lambda k: blur_ops.sparse_blur(list(ordered), idx, tables, 0))
         w2 = timeit(lambda k: blur_ops.sparse_blur(list(ordered), idx, tables, 2))

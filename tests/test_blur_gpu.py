@@ -401,19 +401,19 @@ def test_tile_shapes_and_orders_are_bit_identical():
     O.blur_image_list(want, [{"blurring": True}] * len(imgs), psfs)
     tables = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=True)
     try:
-        for shape, bands in ((2, 1), (1, 1), (1, 0), (0, 1)):
+        for shape, bands in ((1, 1), (1, 0), (0, 1)):
             l.dib_debug_set_shape(shape)
             l.dib_debug_set_tile_order(bands)
             outs = blur_ops.sparse_blur([_dev(a) for a in imgs], list(range(len(imgs))), tables)
             for g, w in zip(outs, want):
                 assert np.array_equal(_bits(g.cpu().numpy().squeeze()), _bits(w)), (shape, bands)
-        # the fused-multiply-add mode: the shapes agree with each other bit for bit
+        # the fused-multiply-add mode: the two shapes agree with each other bit for bit
         fma = []
-        for shape in (0, 1, 2):
+        for shape in (0, 1):
             l.dib_debug_set_shape(shape)
             fma.append(blur_ops.sparse_blur([_dev(a) for a in imgs], list(range(len(imgs))), tables, _lib.DIB_ACC_FMA16))
-        for a, b, c in zip(*fma):
-            assert torch.equal(a, b) and torch.equal(a, c)
+        for a, b in zip(*fma):
+            assert torch.equal(a, b)
     finally:
         l.dib_debug_set_shape(0)
         l.dib_debug_set_tile_order(1)
