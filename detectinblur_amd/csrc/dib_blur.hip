@@ -9,27 +9,24 @@
 //     acc = rnd16(acc + rnd16(P * w))            (v_pk_mul_f16 + v_pk_add_f16, never an FMA)
 // which is bit-identical to the reference's Half tensors.
 //
-// Tiled fp16 kernel -- memory layout in LDS ("split-column" layout):
-//   A workgroup owns a 256 x 32 output tile of ONE channel.  Lane l of every wave owns the four
-//   columns x0 + l + 64k (k = 0..3), packed as two fp16x2 registers per row.  LDS row q holds the
-//   source window row as 8-byte words:  word j = { P[j], P[j+64], P[j+128], P[j+192] },
-//   j in [0, 64+ex), where P is the (virtually padded) source row starting at column
-//   x0 + pb - cmax and ex = cmax - cmin is the column extent of the tap SEGMENT being processed.
-//   A tap (r, c) is then ONE aligned, bank-conflict-free ds_read_b64 at word  lane + (cmax - c)
-//   for ANY column shift -- odd shifts included.  (Measured on MI355X: a ds_read_b64 that is not
-//   8-byte aligned runs 22x slower, so a plain row-major fp16 window is not an option.)
-//   Row shifts are LDS row offsets; the R rows a lane owns use compile-time immediate offsets.
-//   The tap list arrives cut into segments (dib_compact.hip) whose bounding box is at most
-//   17 PSF rows x 33 PSF columns, so ONE small LDS window (48 rows x 96 words = 36 KB, four
-//   workgroups per CU) serves any PSF; a wide or tall PSF simply takes several fill+accumulate
-//   rounds, in tap order, with the accumulators staying in registers.
+// Tiled fp16 kernels -- the "split-column" idea: a lane owns columns a fixed distance apart and the LDS window stores, per
+// position j, the pixels of exactly those columns next to each other.  A tap (r, c) is then one ALIGNED LDS read at
+// position  lane + (cmax - c)  for ANY column shift, odd ones included (measured on MI355X: a ds_read_b64 that is not
+// 8-byte aligned runs 22x slower, so a plain row-major fp16 window is not an option).  Row shifts are LDS row offsets;
+// the rows a lane owns use compile-time immediate offsets.  The tap list arrives cut into segments (dib_compact.hip)
+// whose bounding box is at most 13 PSF rows x 25 PSF columns, so ONE small LDS window serves any PSF: a wide or tall PSF
+// takes several fill + accumulate rounds, in tap order, with the accumulators staying in registers.
+//   default ("quad") shape  128 x 32 tile, lane = 32 h + j owns columns j + {0, 32, 64, 96} of 4 rows, 8-byte elements
+//                           {P[k], P[k+32] | P[k+64], P[k+96]}, 44 rows x 56 elements = 19.7 KB: 8 workgroups per CU
+//   256-wide shape          256 x 32 tile, lane owns columns l + 64k (k = 0..3) of 8 rows, 8-byte words, 44 x 96 words =
+//                           33.8 KB: 4 workgroups per CU; what DIB_ACC_FP32 runs on, and the second implementation the
+//                           tests compare with the default one bit for bit
 //
-// What bounds it (measured, scratch/ubench): a packed fp16 instruction occupies a SIMD for 4 cycles
-// per wave (1.9 ns at the clock the chip holds; 3.2 ns with one wave alone), the same per-element rate as
-// fp32 (MI355X_MICROARCH.md: SIMD-32, v_fma_f32 2 cycles per wave).  The bit-exact contract needs a
-// multiply AND an add per 2 pixel-taps: 15.1 M wave-instructions for the BASELINE batch = ~26 us of
-// pure VALU time on 1024 SIMDs, above its 16 us HBM time.  Everything else -- window fills, stores,
-// launch ramp -- has to hide behind that arithmetic, i.e. behind the other three workgroups of the CU.
+// What bounds it (measured: profiles/r2_blur_tap_slope.txt): a packed fp16 instruction occupies a SIMD for 4 cycles per
+// wave, and the bit-exact contract needs a multiply AND an add per 2 pixel-taps: 16.9 M wave-instructions for the BASELINE
+// batch = 30.8 us of pure vector-ALU time on 1024 SIMDs, above its 13 us of HBM time.  Everything else -- window fills,
+// stores, launch ramp, drain -- has to hide behind that arithmetic, i.e. behind the other workgroups of the CU: hence
+// eight of them per CU, and hence the instruction diet of everything outside the tap loop.
 #include "dib_common.h"
 #include <hip/hip_fp16.h>
 #include <mutex>
