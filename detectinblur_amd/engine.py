@@ -118,6 +118,7 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
         loss_dict_reduced = utils.reduce_dict(loss_dict)                 # logging only
         losses_reduced = sum(loss for loss in loss_dict_reduced.values())
 
+        lr_before = optimizer.param_groups[0]["lr"]        # what the reference's writer logs: read ahead of the warm-up step (:142)
         optimizer.zero_grad()
         losses.backward()
         optimizer.step()
@@ -130,9 +131,14 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
         # stops the run, one step later; the last step is checked behind the loop.
         if deferred is not None:
             _log_step(*deferred)
-        deferred = (metric_logger, writer, losses_reduced, loss_dict_reduced, optimizer.param_groups[0]["lr"],
+        deferred = (metric_logger, writer, losses_reduced, loss_dict_reduced, lr_before, optimizer.param_groups[0]["lr"],
                     iteration_count, epoch, len(data_loader), print_freq)
-        if early_stop is not None and early_stop is not False and iteration_count > early_stop:
+        # reference :160-162, literally: `early_stop=False` (the signature's default) compares as 0 and ends the epoch
+        # after two iterations; train.py passes --early_stop (None unless given).  The iteration that breaks is
+        # logged and checked but, as in the reference, not entered into the meters.
+        if early_stop is not None and iteration_count > early_stop:
+            _log_step(*deferred, update_meters=False)
+            deferred = None
             break
         iteration_count += 1
     if deferred is not None:
@@ -140,36 +146,41 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
     return metric_logger
 
 
-def _log_step(metric_logger, writer, losses_reduced, loss_dict_reduced, lr, iteration_count, epoch, n_iter, print_freq):
-    """reference engine.py:131-158: meters, TensorBoard scalars every 500 iterations, exit on a non-finite loss."""
+def _log_step(metric_logger, writer, losses_reduced, loss_dict_reduced, lr_before, lr_after, iteration_count, epoch, n_iter,
+              print_freq, update_meters=True):
+    """reference engine.py:131-158: TensorBoard scalars every 500 iterations (learning rate as it was BEFORE this
+    iteration's warm-up step), exit on a non-finite loss, meters (learning rate AFTER the step)."""
     loss_value = losses_reduced.item()
     if iteration_count % 500 == 0 and writer is not None and utils.is_main_process() and iteration_count % print_freq == 0:
         step = iteration_count + epoch * n_iter
         for key, v in loss_dict_reduced.items():
             writer.add_scalar("losses/" + key, v, step)
         writer.add_scalar("losses/overallLoss", loss_value, step)
-        writer.add_scalar("learningRate", lr, step)
+        writer.add_scalar("learningRate", lr_before, step)
     if not math.isfinite(loss_value):                                # reference :145-148
         print("Loss is {}, stopping training".format(loss_value))
         print(loss_dict_reduced)
         sys.exit(1)
-    metric_logger.update(loss=losses_reduced, **loss_dict_reduced)
-    metric_logger.update(lr=lr)
+    if update_meters:
+        metric_logger.update(loss=losses_reduced, **loss_dict_reduced)
+        metric_logger.update(lr=lr_after)
 
 
 # ---- ensemble routing (reference engine.py:171-218) ------------------------------------------------
 
 def get_network_index_to_use_oracle(blur_dicts, model_indices):
-    """Ground-truth routing from the blur_dict of the FIRST image: not blurred / very short exposure ->
-    net 0, blur type P1/P2/P3 -> nets 1/2/3."""
+    """Ground-truth routing from the blur_dicts: a sharp image or a very short exposure -> net 0, blur type
+    P1/P2/P3 (`param_index` 0/1/2) -> nets 1/2/3.  The first dict that decides wins; a blurred dict of any other type
+    decides nothing and the next one is asked (None when none is left) -- the reference's loop, engine.py:171-191,
+    pinned over a grid of batches by tests/test_detector_pins.py."""
     for bd in blur_dicts:
-        if bd["blurring"] and bd["param_index"] is not None:
-            if bd["fraction_index"] == -1:
-                return model_indices[0]
-            if bd["param_index"] in (0, 1, 2):
-                return model_indices[bd["param_index"] + 1]
-            return None
-        return model_indices[0]
+        if not (bd["blurring"] and bd["param_index"] is not None):
+            return model_indices[0]
+        if bd["fraction_index"] == -1:
+            return model_indices[0]
+        if bd["param_index"] in (0, 1, 2):
+            return model_indices[bd["param_index"] + 1]
+    return None
 
 
 def get_network_index_to_use_blur_estimator(blur_estimation, model_indices):
@@ -262,8 +273,10 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                     total_boxes += 1
                     if k < len(boxes):
                         ann["bbox"] = boxes[k]
-                    else:
+                    elif k + 1 == len(anns):             # counted once per image, at its last annotation (reference :336-341)
                         faulty_boxes += 1
+                    else:
+                        print("Faulty " + str(len(anns) - k) + " times over.")
         images_GPU = _to_float(images_GPU, ensemble_models[0] if use_ensemble else model, device)
         norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 

@@ -28,7 +28,8 @@ class GeneralizedRCNN(nn.Module):
                 if not isinstance(boxes, torch.Tensor):
                     raise ValueError("Expected target boxes to be of type Tensor, got {:}.".format(type(boxes)))
                 if boxes.dim() != 2 or boxes.shape[-1] != 4:
-                    raise ValueError("Expected target boxes to be a tensor of shape [N, 4], got {:}.".format(boxes.shape))
+                    # the reference's message is two literals joined without a space (generalized_rcnn.py:99-101): kept verbatim
+                    raise ValueError("Expected target boxes to be a tensor" "of shape [N, 4], got {:}.".format(boxes.shape))
         original_sizes = [(int(img.shape[-2]), int(img.shape[-1])) for img in images]
         images, targets = self.transform(images, targets, newMeans, newSTDs)
         # degenerate-box check (reference generalized_rcnn.py:119-129): the flags are computed here, on

@@ -105,3 +105,30 @@ def load_net_transforms():
 
     sys.modules["torchvision.models.detection.image_list"].ImageList = ImageList
     return importlib.import_module("models.net_transforms")
+
+
+_EXTRA_STUBS = ["torchvision.models.detection.transform", "torchvision.models.detection.faster_rcnn"]
+
+
+def load_detector():
+    """The reference's models/faster_rcnn.py and models/generalized_rcnn.py (rows A13 / A14).  What these files
+    define themselves -- constructor defaults, the argument lists handed to the torchvision classes, the control
+    flow of `GeneralizedRCNN.forward` -- runs as is; the torchvision classes they import are MagicMocks that
+    oracle/gen_detector_pins.py replaces by recording fakes (oracle/pin_inputs.py)."""
+    load()
+    for name in _EXTRA_STUBS:
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock(name=name)
+    return importlib.import_module("models.faster_rcnn"), importlib.import_module("models.generalized_rcnn")
+
+
+def load_engine():
+    """The reference's engine.py (`train_one_epoch`, `evaluate`, the three ensemble routers; rows A15 / A17).
+    `coco_eval` / `coco_utils` (pycocotools, `torch._six`) are stubbed: the generator installs a recording
+    evaluator in their place.  engine.py:277 calls `torch.cuda.synchronize()` unconditionally; on this GPU-less
+    container the caller patches it to a no-op for the duration of the call."""
+    load()
+    for name in _EXTRA_STUBS + ["coco_eval", "coco_utils"]:
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock(name=name)
+    return importlib.import_module("engine")

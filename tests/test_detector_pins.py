@@ -1,0 +1,243 @@
+"""Rows A13 / A14 / A15 / A17 against what the REFERENCE'S OWN files do (tests/golden/detector_pins.{json,npz},
+written by oracle/gen_detector_pins.py from /root/reference/models/faster_rcnn.py, models/generalized_rcnn.py and
+engine.py in the build container).  The same recording fakes, toy models and seeded batches (oracle/pin_inputs.py)
+are driven through this repo's classes here; torchvision's numerics stay unpinned by construction."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pin_inputs as PI
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def pins():
+    with open(os.path.join(GOLD, "detector_pins.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def arrays():
+    return np.load(os.path.join(GOLD, "detector_pins.npz"))
+
+
+def _json(x):
+    return json.loads(json.dumps(x))
+
+
+# ---- A14: what fasterrcnn_resnet50_fpn hands to its parts (reference models/faster_rcnn.py:144-243, 301-373) --------
+
+@pytest.mark.parametrize("name", list(PI.detector_ctor_cases()))
+def test_constructor_calls_equal_the_reference(pins, name, monkeypatch):
+    from detectinblur_amd.models import faster_rcnn as FR
+    log = []
+    for k, v in PI.detector_fakes(log).items():
+        monkeypatch.setattr(FR, k, v)
+    # the trunk file the reference would download: this repo loads it itself from a local cache (no network)
+    monkeypatch.setattr(FR, "find_pretrained", lambda kind: "/nonexistent/%s.pth" % kind)
+    monkeypatch.setattr(FR.torch, "load", lambda *a, **k: {"conv1.weight": 0, "fc.weight": 0, "fc.bias": 0})
+    model = FR.fasterrcnn_resnet50_fpn(**PI.detector_ctor_cases()[name])
+    want = pins["ctor"][name]
+    mine = [c for c in _json(log) if c[0] != "body.load_state_dict"]
+    assert [c[0] for c in mine] == [c[0] for c in want["calls"]]
+    for got, ref in zip(mine, want["calls"]):
+        if got[0] == "resnet_fpn_backbone":
+            # reference: (name, pretrained_flag, trainable_layers=); here the flag is always False (weights are loaded
+            # from the cached file afterwards) -- name and the trainable-layer rule (:361-363) must agree
+            assert got[1][0] == ref[1][0] and got[2] == ref[2]
+            if ref[1][1]:
+                assert any(c[0] == "body.load_state_dict" for c in log)
+                assert not any(k.startswith("fc.") for c in log if c[0] == "body.load_state_dict" for k in c[1])
+        else:
+            assert got == ref, got[0]
+    got_model = {"backbone": PI.describe(model.backbone), "rpn": PI.describe(model.rpn), "roi_heads": PI.describe(model.roi_heads),
+                 "transform": PI.describe(model.transform), "warp_internally": bool(model.warp_internally),
+                 "has_warper": hasattr(model, "warper")}
+    assert got_model == want["model"]
+
+
+def test_real_modules_keep_the_recorded_hyperparameters(pins):
+    """The arguments recorded above end up in the attributes this repo's RPN / RoIHeads / transform really read."""
+    from detectinblur_amd.models.faster_rcnn import fasterrcnn_resnet50_fpn
+    calls = {c[0]: c for c in pins["ctor"]["random_init_default"]["calls"]}
+    m = fasterrcnn_resnet50_fpn(num_classes=91, pretrained=False, pretrained_backbone=False)
+    a = calls["AnchorGenerator"][1]
+    assert _json(m.rpn.anchor_generator.sizes) == a[0] and _json(m.rpn.anchor_generator.aspect_ratios) == a[1]
+    assert m.rpn.head.cls_logits.out_channels == calls["RPNHead"][1][1] and m.rpn.head.conv.in_channels == calls["RPNHead"][1][0]
+    _, _, fg, bg, bs, pf, pre, post, nms = calls["RegionProposalNetwork"][1]
+    assert (m.rpn.matcher.high, m.rpn.matcher.low) == (fg, bg) and m.rpn.matcher.allow_low
+    assert (m.rpn.batch_size_per_image, m.rpn.positive_fraction, m.rpn.nms_thresh) == (bs, pf, nms)
+    assert m.rpn._pre == pre and m.rpn._post == post
+    r = calls["MultiScaleRoIAlign"][2]
+    assert m.roi_heads.box_roi_pool.featmap_names == r["featmap_names"] and m.roi_heads.box_roi_pool.sampling_ratio == r["sampling_ratio"]
+    assert m.roi_heads.box_roi_pool.output_size == (r["output_size"],) * 2
+    _, head, pred, fg, bg, bs, pf, regw, score, nms, dets = calls["RoIHeads"][1]
+    assert {k: list(v.shape) for k, v in m.roi_heads.box_head.state_dict().items()} == head["params"]
+    assert {k: list(v.shape) for k, v in m.roi_heads.box_predictor.state_dict().items()} == pred["params"]
+    assert (m.roi_heads.matcher.high, m.roi_heads.matcher.low) == (fg, bg)
+    assert not m.roi_heads.matcher.allow_low
+    assert (m.roi_heads.batch_size_per_image, m.roi_heads.positive_fraction) == (bs, pf)
+    assert regw is None and tuple(m.roi_heads.box_coder.weights) == (10.0, 10.0, 5.0, 5.0)     # torchvision's default for None
+    assert (m.roi_heads.score_thresh, m.roi_heads.nms_thresh, m.roi_heads.detections_per_img) == (score, nms, dets)
+    t = calls["GeneralizedRCNNTransform"][1]
+    assert (m.transform.min_size, m.transform.max_size) == ((t[0],), t[1])
+    assert list(m.transform.image_mean) == t[2] and list(m.transform.image_std) == t[3]
+    # nothing frozen without pretrained weights (reference :361-363)
+    assert calls["resnet_fpn_backbone"][2]["trainable_layers"] == 5
+    assert all(p.requires_grad for p in m.backbone.body.parameters())
+
+
+# ---- A13: GeneralizedRCNN.forward (reference models/generalized_rcnn.py:78-161) ------------------------------------------
+
+@pytest.mark.parametrize("name", list(PI.forward_cases()))
+def test_generalized_rcnn_forward_equals_the_reference(pins, name):
+    from detectinblur_amd.models.generalized_rcnn import GeneralizedRCNN
+    got = _json(PI.run_forward_case(GeneralizedRCNN, PI.forward_cases()[name]))
+    want = pins["forward"][name]
+    assert got["error"] == want["error"]
+    assert got["result"] == want["result"]
+    if "degenerate" in name:
+        # same ValueError; this repo raises it once the forward pass is enqueued (no host wait in front of the
+        # backbone), the reference right behind the transform: the log up to that point agrees
+        assert got["log"][:len(want["log"])] == want["log"]
+    else:
+        assert got["log"] == want["log"]
+
+
+# ---- A17: the three ensemble routers (reference engine.py:171-218) ---------------------------------------------------------
+
+def test_routers_equal_the_reference_on_the_grid(pins):
+    from detectinblur_amd import engine
+    labels = ["n0", "n1", "n2", "n3"]
+    got = [engine.get_network_index_to_use_oracle(b, labels) for b in PI.router_oracle_batches()]
+    assert got == pins["router_oracle"]
+    assert None in got and "n3" in got               # the grid reaches the fall-through and every net
+    idx = [0, 1, 2, 3]
+    assert [engine.get_network_index_to_use_blur_estimator(e, idx) for e in PI.router_estimations()] == pins["router_estimator"]
+    assert [engine.get_network_index_to_use_blur_estimator_LEHE(e, idx) for e in PI.router_estimations()] == pins["router_estimator_lehe"]
+
+
+# ---- A15: train_one_epoch (reference engine.py:30-167) ---------------------------------------------------------------------
+
+_TRAIN_KW = {"plain": (False, dict(early_stop=None)), "blur": (True, dict(early_stop=None)),
+             "blur_epoch1": (True, dict(early_stop=None, epoch=1)), "default_early_stop": (False, dict()),
+             "early_stop_2": (False, dict(early_stop=2))}
+
+
+def _run_train(name, device):
+    from detectinblur_amd import engine
+    blur, kw = _TRAIN_KW[name]
+    kw = dict(kw)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = PI.ToyDetector(1).to(device)
+    opt = torch.optim.SGD(model.parameters(), lr=0.04, momentum=0.9, weight_decay=1e-4)
+    model.lr_probe = opt
+    writer = PI.RecordingWriter()
+    losses = []
+    hook = model.register_forward_hook(lambda m, i, o: losses.append({k: float(v.detach()) for k, v in o.items()}))
+    with contextlib.redirect_stdout(io.StringIO()):
+        engine.train_one_epoch(model, opt, PI.train_batches(blur), device, epoch=kw.pop("epoch", 0), print_freq=2, writer=writer,
+                               distributed_mode=True, blur_train=blur, gpu_blur=blur, expand_target_boxes=blur,
+                               use_custom_image_norm=blur, **kw)
+    hook.remove()
+    return model, opt, writer, losses
+
+
+def _check_train(name, device, pins, arrays, tol):
+    model, opt, writer, losses = _run_train(name, device)
+    want = pins["train"][name]
+    assert len(model.calls) == want["steps"]
+    assert [c["lr"] for c in model.calls] == pytest.approx(want["lr_seen_by_forward"], rel=1e-12)
+    assert opt.param_groups[0]["lr"] == pytest.approx(want["final_lr"], rel=1e-12)
+    for got, ref in zip(model.calls, want["calls"]):
+        for k in ("thetas", "lambda1s", "lambda2s", "dtypes", "killWarp"):
+            assert got[k] == ref[k], k
+    for got, ref in zip(losses, want["losses"]):
+        assert list(got) == list(ref)                                   # key order of the loss dict
+        for k in ref:
+            assert got[k] == pytest.approx(ref[k], abs=tol, rel=tol)
+    assert [(s[0], s[2]) for s in writer.scalars] == [(s[0], s[2]) for s in want["scalars"]]
+    for got, ref in zip(writer.scalars, want["scalars"]):
+        assert got[1] == pytest.approx(ref[1], abs=tol, rel=tol), got[0]
+    for k, v in model.state_dict().items():
+        ref = arrays["train_%s_%s" % (name, k)]
+        assert np.allclose(v.detach().cpu().numpy(), ref, atol=tol, rtol=tol), k
+
+
+@pytest.mark.parametrize("name", ["plain", "default_early_stop", "early_stop_2"])
+def test_train_one_epoch_equals_the_reference_cpu(pins, arrays, name):
+    """No blur (this package has no CPU blur path): optimiser / warm-up / early-stop / logging mechanics."""
+    _check_train(name, torch.device("cpu"), pins, arrays, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(_TRAIN_KW))
+def test_train_one_epoch_equals_the_reference_gpu(pins, arrays, name):
+    """The whole step -- H2D as Half, HIP blur, HIP box growth, float, custom normalisation rows, toy forward /
+    backward, SGD with warm-up -- against the reference's own train_one_epoch run on CPU on the same batches:
+    weights after 5 steps, every loss, the LR trajectory and the TensorBoard scalars within 1e-5."""
+    _check_train(name, torch.device("cuda"), pins, arrays, 1e-5)
+
+
+# ---- A17: evaluate (reference engine.py:220-416) -----------------------------------------------------------------------------
+
+def _run_eval(name, device, monkeypatch):
+    from detectinblur_amd import coco_eval, coco_utils, engine
+    case = PI.eval_cases()[name]
+    loader = PI.eval_batches(case["blur"])
+    coco = PI.FakeCoco(loader, extra_ann_for=(101,))
+    monkeypatch.setattr(coco_eval, "CocoEvaluator", PI.FakeCocoEvaluator)
+    monkeypatch.setattr(coco_utils, "get_coco_api_from_dataset", lambda ds: coco)
+    model, ens, est = PI.build_eval_models(case, device)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ret = engine.evaluate(model, loader, device, distributed_mode=True, ensemble_models=ens, blur_estimator=est, **case["kw"])
+    return ret, PI.FakeCocoEvaluator.last, coco, model, ens, est, buf.getvalue()
+
+
+def _check_eval(name, device, pins, arrays, monkeypatch, tol):
+    ret, ev, coco, model, ens, est, text = _run_eval(name, device, monkeypatch)
+    want = pins["eval"][name]
+    assert ret.coco_gt is coco                          # the evaluator surface the reference returns (engine.py:416)
+    assert ev.calls == want["evaluator_calls"]
+    assert ev.img_ids == want["image_ids"]
+    if ens:
+        assert PI.routes_of(ens) == want["routes"]
+    for b, upd in enumerate(ev.updates):
+        for iid, o in upd.items():
+            assert sorted(o) == ["boxes", "labels", "scores"]
+            for n, v in o.items():
+                ref = arrays["eval_%s_%d_%d_%s" % (name, b, iid, n)]
+                assert v.dtype == ref.dtype and np.allclose(v, ref, atol=tol, rtol=tol), (b, iid, n)
+    gt = {str(iid): [a["bbox"] for a in anns] for iid, anns in coco.imgToAnns.items()}
+    assert list(gt) == list(want["gt_bbox"])
+    for iid in gt:
+        assert np.allclose(np.array(gt[iid]), np.array(want["gt_bbox"][iid]), atol=0, rtol=0), iid    # HIP box growth is bit-exact
+    for got_m, ref_m in zip([m.calls for m in (ens or [model])], want["model_calls"]):
+        assert len(got_m) == len(ref_m)
+        for g, r in zip(got_m, ref_m):
+            for k in ("thetas", "lambda1s", "lambda2s", "dtypes", "killWarp", "training"):
+                assert g[k] == r[k], k
+    if est is not None:
+        assert _json(est.calls) == [dict(c, sum=pytest.approx(c["sum"], abs=1e-2)) for c in want["estimator_calls"]]
+    assert [ln for ln in text.splitlines() if ln.startswith("Number of Faulty boxes")] == want["faulty_line"]
+
+
+def test_evaluate_equals_the_reference_cpu(pins, arrays, monkeypatch):
+    _check_eval("single_vanilla", torch.device("cpu"), pins, arrays, monkeypatch, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(PI.eval_cases()))
+def test_evaluate_equals_the_reference_gpu(pins, arrays, monkeypatch, name):
+    """H2D, HIP blur, HIP box growth written into the ground truth, routing (oracle / 4-way / 16-way estimator behind
+    the crop batcher), the call into the chosen detector and what reaches the COCO evaluator, against the reference's
+    own `evaluate` run on CPU on the same batches."""
+    _check_eval(name, torch.device("cuda"), pins, arrays, monkeypatch, 1e-5)
