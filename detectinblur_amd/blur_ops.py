@@ -171,6 +171,9 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
 # side stream as soon as they are on the device, it overlaps whatever the main stream is still doing -- the previous
 # batch's detector in a training loop, the previous batch's blur in bench.py -- and the blur only waits for its
 # event.  Tables made this way carry `.ready`; sparse_blur / expand_boxes wait on it before they read the tables.
+# Tables are plain objects owned by whoever made them (engine.py hands one set per batch to blur_image_list and
+# expand_targets through `tables=`): there is no process-wide table cache, so a PSF buffer rewritten in place by a raw
+# kernel (dib_psf_rasterize into a reused tensor) can never meet tables compacted from its previous contents.
 _side_streams = {}
 
 
@@ -196,6 +199,10 @@ def compact_psfs_ahead(psfs, normalize, after_current=True):
         tabs = compact_psfs(psfs, normalize)
         tabs.ready = torch.cuda.Event()
         tabs.ready.record(side)
+    # the PSFs were allocated on the main stream and are read on the side stream: tell the caching allocator, or a
+    # buffer freed right after this call could be handed out again while the compaction still reads it
+    for p in (psfs if isinstance(psfs, (list, tuple)) else (psfs,)):
+        p.record_stream(side)
     return tabs
 
 
@@ -206,42 +213,6 @@ def _await(tables):
         cur = torch.cuda.current_stream(tables.buf.device)
         cur.wait_event(ev)
         tables.buf.record_stream(cur)      # the buffer came from the side stream's pool
-
-
-# One-entry cache: the engine calls blur_image_list and then expand_targets with the same PSF
-# tensors (reference engine.py:101-105); the second call reuses the tables of the first instead
-# of re-running normalise + nonzero as the reference does (utils.py:372-374).
-_cache = {"key": None, "tables": None}
-
-
-def invalidate_cache():
-    _cache["key"] = _cache["tables"] = None
-    _cache.pop("pin", None)
-
-
-def _cache_key(psfs, normalize):
-    return (bool(normalize),) + tuple((p.data_ptr(), p._version, p.dtype, tuple(p.shape)) for p in psfs)
-
-
-def precompact(psfs, normalize=True, after_current=True):
-    """Start the compaction of these PSF tensors on the side stream now and remember the tables: the
-    blur_image_list / expand_targets calls that follow with the same tensors find them (engine.py does this right
-    behind the PSFs' host-to-device copy, while the GPU is still busy with the previous batch)."""
-    tabs = compact_psfs_ahead(psfs, normalize, after_current)
-    _cache["key"], _cache["tables"] = _cache_key(psfs, normalize), tabs
-    _cache["pin"] = list(psfs)
-    return tabs
-
-
-def compact_psfs_cached(psfs, normalize):
-    key = _cache_key(psfs, normalize)
-    if _cache["key"] == key:
-        return _cache["tables"]
-    tabs = compact_psfs(psfs, normalize)
-    _cache["key"], _cache["tables"] = key, tabs
-    # keep the PSF tensors alive while cached so a recycled data_ptr cannot alias the key
-    _cache["pin"] = list(psfs)
-    return tabs
 
 
 def expand_boxes(boxes, tables, index, H, W):

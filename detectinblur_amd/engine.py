@@ -21,8 +21,11 @@ from . import utils
 from .models import blur_functions, net_transforms
 
 
-def _to_device(images_CPU, targets, blur_dicts, device, blurring):
+def _to_device(images_CPU, targets, blur_dicts, device, blurring, want_tables=True):
     """reference engine.py:79-98: images as Half, PSFs via torch.HalfTensor(ndarray).
+    Returns (images, targets, psfs, thetas, lambda1s, lambda2s, tables): `tables` are the batch's tap tables, being
+    compacted on the side stream (None when nothing will consume them, on the CPU, or for PSFs of mixed shapes) --
+    the caller hands them to `blur_image_list(tables=)` and `expand_targets(tables=)`.
     On a GPU the fp32 tensor the DataLoader pinned is uploaded as is (a true asynchronous copy) and rounded to
     Half on the device -- the same round-to-nearest-even as `.half()` on the host, without the pageable
     intermediate that made the copy host-synchronous."""
@@ -31,7 +34,7 @@ def _to_device(images_CPU, targets, blur_dicts, device, blurring):
     else:
         images_GPU = [image.half() for image in images_CPU]
     targets_GPU = [{k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in t.items()} for t in targets]
-    psfs_GPU = thetas = l1 = l2 = None
+    psfs_GPU = thetas = l1 = l2 = tables = None
     if blurring:
         cuda = device.type == "cuda"
         # PSFs: torch.HalfTensor(ndarray) (float64 -> float32 -> float16) into ONE pinned staging block per
@@ -53,19 +56,25 @@ def _to_device(images_CPU, targets, blur_dicts, device, blurring):
             if psfs_GPU[i] is None:
                 psfs_GPU[i] = h.to(device, non_blocking=True)
         # tap compaction starts now, on the side stream: it overlaps the image conversion above and whatever the
-        # previous batch still has on the GPU; blur_image_list / expand_targets pick the tables up from the cache
-        blurring = [p for p, bd in zip(psfs_GPU, blur_dicts) if bd["blurring"]]
-        if cuda and blurring and len({tuple(p.shape) for p in blurring}) == 1 and blurring[0].dim() == 2 \
-                and blurring[0].shape[0] in (128, 256):
+        # previous batch still has on the GPU; only when a blur or a box growth will wait for it
+        active = [p for p, bd in zip(psfs_GPU, blur_dicts) if bd["blurring"]]
+        if want_tables and cuda and active and len({tuple(p.shape) for p in active}) == 1 and active[0].dim() == 2 \
+                and active[0].shape[0] in (128, 256):
             from . import blur_ops
-            blur_ops.precompact(blurring, normalize=True, after_current=True)
+            tables = blur_ops.compact_psfs_ahead(active, normalize=True, after_current=True)
         # theta / lambda1 / lambda2: one [3, B] pinned tensor, one copy
         scal = torch.tensor([[bd["theta_rad"] for bd in blur_dicts], [bd["scale_factor_lambda1"] for bd in blur_dicts],
                              [bd["scale_factor_lambda2"] for bd in blur_dicts]], dtype=torch.float16)
         if cuda:
             scal = scal.pin_memory().to(device, non_blocking=True)
         thetas, l1, l2 = scal[0], scal[1], scal[2]
-    return images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2
+    return images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables
+
+
+def _tables_128(tables):
+    """expand_targets refuses PSFs that are not 128 wide with the reference's own exception (utils.py:369-370): let it
+    see the PSFs, not tables of another canvas."""
+    return tables if tables is not None and tables.K == 128 else None
 
 
 def _to_float(images_GPU, model, device):
@@ -102,13 +111,14 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
     iteration_count = 0
     deferred = None
     for images_CPU, targets, blur_dicts in metric_logger.log_every(data_loader, print_freq, header):
-        images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2 = _to_device(images_CPU, targets, blur_dicts, device, blur_train)
+        images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables = _to_device(
+            images_CPU, targets, blur_dicts, device, blur_train, want_tables=gpu_blur or expand_target_boxes)
         if gpu_blur and blur_train:
             blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU=psfs_GPU, add_noise=add_noise,
                                            noise_level=noise_level, add_block=add_block,
-                                           add_jpeg_artifact=add_jpeg_artifact, jpeg_compressor=jpeg_compressor)
+                                           add_jpeg_artifact=add_jpeg_artifact, jpeg_compressor=jpeg_compressor, tables=tables)
         if expand_target_boxes and blur_train:
-            targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU)
+            targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU, tables=_tables_128(tables))
         images_GPU = _to_float(images_GPU, model, device)
         norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 
@@ -257,13 +267,14 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
         if device.type == "cuda":
             torch.cuda.synchronize()
         model_time = time.time()
-        images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2 = _to_device(images_CPU, targets_CPU, blur_dicts, device, blurring_images)
+        images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables = _to_device(
+            images_CPU, targets_CPU, blur_dicts, device, blurring_images, want_tables=gpu_blur or expand_target_boxes)
         if gpu_blur and blurring_images:
             blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU=psfs_GPU, add_noise=add_noise, noise_level=noise_level,
                                            add_block=add_block, add_jpeg_artifact=add_jpeg_artifact,
-                                           jpeg_compressor=jpeg_compressor)
+                                           jpeg_compressor=jpeg_compressor, tables=tables)
         if expand_target_boxes and blurring_images:
-            targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU)
+            targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU, tables=_tables_128(tables))
             # the expanded boxes replace the ground truth's, annotation k <- target box k (reference :325-342,
             # index-wise: where the target dropped a crowd / degenerate annotation the tail keeps its box)
             for target in targets_GPU:

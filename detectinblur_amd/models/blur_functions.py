@@ -63,7 +63,8 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_lev
     """In place: images_GPU[i] is replaced by its blurred version when blur_dicts[i]["blurring"].
     PSFs arrive un-normalised and are divided by their sum here (reference :98).  Returns None.
     `tables` (beyond the reference's signature): tap tables of exactly the blurring PSFs, in order, compacted ahead
-    of time with blur_ops.compact_psfs_ahead (normalize=True) -- the compaction then overlaps earlier GPU work."""
+    of time with blur_ops.compact_psfs_ahead (normalize=True) -- the compaction then overlaps earlier GPU work, and
+    `utils.expand_targets(..., tables=)` can share them.  Without it the PSFs are compacted here, every call."""
     idx = [i for i, bd in enumerate(blur_dicts) if bd["blurring"]]
     if not idx:
         return None
@@ -100,7 +101,7 @@ def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=Non
     if tables is None:
         psfs = [psfs_GPU[i] if psfs_GPU[i].dtype == images_GPU[i].dtype else psfs_GPU[i].to(images_GPU[i].dtype)
                 for i in idx]
-        tables = blur_ops.compact_psfs_cached(psfs, normalize=True)
+        tables = blur_ops.compact_psfs(psfs, normalize=True)
     # Scheduling hint (optional, host-side, never needed for correctness): `BlurImage` records the PSF's
     # tap count in blur_dict["psf_taps"].  Tiles are dispatched in descriptor order, so handing the
     # images over heaviest first lets the launch end on its cheapest tiles (~4 % at BASELINE shapes).

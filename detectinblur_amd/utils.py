@@ -14,9 +14,11 @@ from . import blur_ops
 # ---------------------------------------------------------------------------------------------
 
 
-def expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU):
+def expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU, tables=None):
     """Grows every ground-truth box by the PSF's non-zero extent, then clamps (in place on
-    target["boxes"]; returns the same list).  Reference utils.py:360-392."""
+    target["boxes"]; returns the same list).  Reference utils.py:360-392.
+    `tables` (beyond the reference's signature): the tap tables of exactly the blurring PSFs, in order, as handed to
+    `blur_image_list(..., tables=)`; without it the extents are recomputed from `psfs_GPU`, as the reference does."""
     idx = [i for i, bd in enumerate(blur_dicts) if bd["blurring"]]
     if not idx:
         return targets_GPU
@@ -24,13 +26,17 @@ def expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU):
         # "This function is not flexible on purpose" (utils.py:366-370)
         if psfs_GPU[i].shape[0] != 128:
             raise Exception("Trying to expand with filters that are not 128 wide!")
-    psfs = []
-    for i in idx:
-        p, img = psfs_GPU[i], images_GPU[i]
-        psfs.append(p if p.dtype in (torch.float16, torch.float32) else p.float())
-    if len({p.dtype for p in psfs}) != 1:
-        psfs = [p.float() for p in psfs]
-    tables = blur_ops.compact_psfs_cached(psfs, normalize=True)
+    if tables is not None:
+        if tables.count != len(idx) or tables.K != 128:
+            raise ValueError("tables do not belong to the blurring PSFs of this batch")
+    else:
+        psfs = []
+        for i in idx:
+            p = psfs_GPU[i]
+            psfs.append(p if p.dtype in (torch.float16, torch.float32) else p.float())
+        if len({p.dtype for p in psfs}) != 1:
+            psfs = [p.float() for p in psfs]
+        tables = blur_ops.compact_psfs(psfs, normalize=True)
     for k, i in enumerate(idx):
         boxes = targets_GPU[i]["boxes"]
         shape = images_GPU[i].shape
