@@ -17,7 +17,7 @@ from .coco_utils import get_coco
 from .engine import evaluate
 from .models.blur_estimator import resnet18
 from .models.faster_rcnn import fasterrcnn_resnet50_fpn
-from .train import _seed_worker, add_shared_flags, get_transform, log_coco_stats, reject_out_of_scope, seed_everything
+from .train import _seed_worker, add_shared_flags, detector_size_kwargs, get_transform, log_coco_stats, reject_out_of_scope, seed_everything
 
 SWEEP_PARAMS = [0.005, 0.001, 0.00005]
 SWEEP_FRACTIONS = [1 / 25, 1 / 10, 1 / 5, 1 / 2, 1]
@@ -68,7 +68,7 @@ def main(args):
 
     def detector(path=None):
         m = _load(fasterrcnn_resnet50_fpn(num_classes=91, pretrained=args.pretrained, pretrained_backbone=False,
-                                          warp_internally=args.warp_in_model), path).to(device)
+                                          warp_internally=args.warp_in_model, **detector_size_kwargs(args)), path).to(device)
         if not args.distributed:
             return m
         return torch.nn.parallel.DistributedDataParallel(m, device_ids=[args.gpu] if device.type == "cuda" else None,

@@ -73,12 +73,14 @@ def reject_out_of_scope(args):
 
 def add_shared_flags(p):
     """Flags train.py and evaluate.py share (reference train.py:399-478, evaluate.py:384-466), same names,
-    defaults and help texts' meaning; `--synthetic*` / `--stored_psf_count` are this repo's additions."""
+    defaults and help texts' meaning; `--synthetic*` / `--stored_psf_count` / `--min_size` / `--max_size` are this repo's additions."""
     p.add_argument("--dataset", default="coco", help="dataset")
     p.add_argument("--data_path", default=None, help="COCO root (train2017/, val2017/, annotations/)")
     p.add_argument("--synthetic", action="store_true", help="COCO-shaped synthetic data (no dataset on disk needed)")
     p.add_argument("--synthetic_images", default=64, type=int)
     p.add_argument("--synthetic_size", default=[800, 1333], nargs=2, type=int)
+    p.add_argument("--min_size", default=None, type=int, help="(this repo) FasterRCNN(min_size=), reference default 800 (models/faster_rcnn.py:148)")
+    p.add_argument("--max_size", default=None, type=int, help="(this repo) FasterRCNN(max_size=), reference default 1333")
     p.add_argument("--use_stored_psfs", action="store_true", help="Use stored PSFs when blurring in the data loader.")
     p.add_argument("--stored_psf_directory", default=None, help="Stored PSFs path.")
     p.add_argument("--stored_psf_count", default=T.STORED_PSF_COUNT, type=int)
@@ -115,6 +117,11 @@ def add_shared_flags(p):
     p.add_argument("--world-size", default=1, type=int, help="number of distributed processes")
     p.add_argument("--dist-url", default="env://", help="url used to set up distributed training")
     return p
+
+
+def detector_size_kwargs(args):
+    """--min_size / --max_size as FasterRCNN keyword arguments (absent: the reference's 800 / 1333)."""
+    return {k: getattr(args, k) for k in ("min_size", "max_size") if getattr(args, k, None) is not None}
 
 
 def build_parser():
@@ -202,7 +209,7 @@ def main(args):
     model = fasterrcnn_resnet50_fpn(num_classes=num_classes, pretrained=args.pretrained,
                                     pretrained_backbone=False if args.synthetic else "auto",
                                     trainable_backbone_layers=args.trainable_backbone_blocks,
-                                    warp_internally=args.warp_in_model)
+                                    warp_internally=args.warp_in_model, **detector_size_kwargs(args))
     model.to(device)
     model_without_ddp = model
     if args.distributed:
