@@ -78,6 +78,9 @@ def blur_cases():
     add("full_e1_f16", (3, 800, 1333), "float16", 1337, ("golden", 0.005, 1), digest_only=True)
     add("full_e2_f16", (3, 800, 1333), "float16", 1338, ("golden", 0.005, 2), digest_only=True)
     add("coco_e2_f16", (3, 480, 640), "float16", 1339, ("golden", 0.001, 2), digest_only=True)
+    # configs[4]'s heaviest cells: full exposure, ~200-250 taps in several LDS segments (round 3)
+    add("full_e4_f16", (3, 800, 1333), "float16", 1340, ("golden", 0.005, 4), digest_only=True)
+    add("full_e4_p3_f16", (3, 800, 1333), "float16", 1341, ("golden", 0.00005, 4), digest_only=True)
     return c
 
 
