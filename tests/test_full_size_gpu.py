@@ -82,7 +82,7 @@ def test_train_main_full_size_stored_psfs(tmp_path, monkeypatch, capsys):
     assert all(p.shape == (128, 128) for p, d in zip(rec["psfs"], rec["dicts"]) if d["blurring"])
     # 5 training batches (early_stop 3 ends the epoch on its 5th iteration) + 4 blurred evaluation images
     assert rec["calls"] == 5 + 4
-    assert text.count("Epoch: [0]") >= 5 and "loss" in text
+    assert text.count("Epoch: [0]") >= 4 and "loss" in text      # the iteration that breaks prints no progress line
     ck = torch.load(out_dir / "model_0.pth", map_location="cpu", weights_only=False)
     assert ck["epoch"] == 0 and all(torch.isfinite(v).all() for v in ck["model"].values() if v.is_floating_point())
     assert text.count("IoU metric: bbox") == 2         # the clean and the blurred evaluation pass (train.py:345-387)
