@@ -32,14 +32,24 @@ class GeneralizedRCNN(nn.Module):
                     raise ValueError("Expected target boxes to be a tensor" "of shape [N, 4], got {:}.".format(boxes.shape))
         original_sizes = [(int(img.shape[-2]), int(img.shape[-1])) for img in images]
         images, targets = self.transform(images, targets, newMeans, newSTDs)
-        # degenerate-box check (reference generalized_rcnn.py:119-129): the flags are computed here, on
-        # the device, but READ only once the whole forward pass has been enqueued -- reading them first would
-        # stall the host behind the previous step's backward and leave the GPU idle while the
-        # forward pass is issued.  Same ValueError, raised before anything is returned.
-        degenerate = None
+        # degenerate-box check (reference generalized_rcnn.py:119-129).  The flag is computed on the device right here
+        # and copied to pinned host memory behind the transform; it is READ only once the whole forward pass has been
+        # enqueued, after waiting for that copy alone -- the GPU reaches it before it starts the backbone, so the host
+        # neither stalls behind the forward pass nor leaves the queue empty when it goes on to issue the backward pass
+        # (a plain `bool(flag)` at either place drains the queue once per step).  Same ValueError, raised before
+        # anything is returned.
+        degenerate = flag_ready = None
         if targets is not None:
             flags = [(t["boxes"][:, 2:] <= t["boxes"][:, :2]).any() for t in targets]
-            degenerate = torch.stack(flags) if flags else None
+            if flags:
+                degenerate = torch.stack(flags).any()
+                if degenerate.is_cuda:
+                    if getattr(self, "_flag_host", None) is None:
+                        self._flag_host = torch.zeros((), dtype=torch.bool).pin_memory()
+                    self._flag_host.copy_(degenerate, non_blocking=True)
+                    flag_ready = torch.cuda.Event()
+                    flag_ready.record()
+                    degenerate = self._flag_host
         if self.warp_internally and not killWarp:
             # squint: stretch along the blur axes, run the trunk, un-stretch every pyramid level
             features = self.backbone(self.warper(images.tensors, thetas, lambda1s, lambda2s))
@@ -54,7 +64,9 @@ class GeneralizedRCNN(nn.Module):
         proposals, proposal_losses = self.rpn(images, features, targets)
         detections, detector_losses = self.roi_heads(features, proposals, images.image_sizes, targets)
         detections = self.transform.postprocess(detections, images.image_sizes, original_sizes)
-        if degenerate is not None and bool(degenerate.any()):
+        if flag_ready is not None:
+            flag_ready.synchronize()
+        if degenerate is not None and bool(degenerate):
             for idx, target in enumerate(targets):
                 boxes = target["boxes"]
                 bad = boxes[:, 2:] <= boxes[:, :2]

@@ -117,3 +117,18 @@ def test_train_cli_with_full_corruption_chain(tmp_path, capsys):
     train.main(args)
     text = capsys.readouterr().out
     assert "loss_classifier" in text and "Loss is" not in text
+
+
+def test_degenerate_boxes_raise_on_the_gpu_without_draining_the_queue():
+    """The degenerate-box flag travels to pinned host memory behind the transform and is read at the end of forward
+    (reference models/generalized_rcnn.py:119-129: same ValueError, same text)."""
+    m = _model()
+    m.train()
+    imgs = [torch.rand(3, 150, 210, device="cuda"), torch.rand(3, 150, 210, device="cuda")]
+    good = {"boxes": torch.tensor([[10., 20., 60., 70.]], device="cuda"), "labels": torch.tensor([3], device="cuda")}
+    bad = {"boxes": torch.tensor([[5., 5., 50., 60.], [30., 40., 30., 90.]], device="cuda"), "labels": torch.tensor([1, 2], device="cuda")}
+    means = np.tile([0.485, 0.456, 0.406], (2, 1)); stds = np.tile([0.229, 0.224, 0.225], (2, 1))
+    with pytest.raises(ValueError, match=r"positive height and width. Found invaid box \[.*\] for target at index 1"):
+        m(imgs, [good, bad], newMeans=means, newSTDs=stds)
+    losses = m(imgs, [good, good], newMeans=means, newSTDs=stds)          # and the flag is clean again on the next call
+    assert all(torch.isfinite(v) for v in losses.values())
