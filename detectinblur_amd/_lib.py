@@ -67,6 +67,9 @@ _SIGNATURES = {
                                         ctypes.c_void_p, ctypes.c_void_p]),
     "dib_bias_act_nhwc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_void_p]),
+    "dib_bias_act_mask_nhwc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_relu_mask_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]),
     # test hook, not part of the drop-in boundary
     "dib_sparse_blur_generic": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
@@ -93,7 +96,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.dib_abi_version() != 3:
+        if l.dib_abi_version() != 4:
             raise ImportError("libdib_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -130,7 +130,7 @@ def _coco_remove_images_without_annotations(dataset, cat_list=None):
 
 
 class SyntheticCocoDetection(torch.utils.data.Dataset):
-    """Seeded random images + boxes: image i is `torch.rand(3, H, W)` from generator seed `seed + i`;
+    """Seeded random images + boxes from generator seed `seed + i`: the boxes first, then image i = `torch.rand(3, H, W)`;
     `boxes_per_image` boxes with x1, y1 uniform and w, h uniform in [32, 400] clipped to the image,
     labels uniform in 1..num_classes-1."""
 
@@ -159,8 +159,8 @@ class SyntheticCocoDetection(torch.utils.data.Dataset):
     def __getitem__(self, idx):
         H, W = self.size
         g = torch.Generator().manual_seed(self.seed + idx)
+        target = self._target(idx, g)             # drawn first: `annotations` below then needs none of the image's draws
         img = torch.rand(3, H, W, generator=g)
-        target = self._target(idx, g)
         if not self.as_tensor:   # PIL image, as CocoDetection hands to the transforms (needed by --cpu_blur)
             from PIL import Image
             img = Image.fromarray((img.permute(1, 2, 0).numpy() * 255).astype(np.uint8))
@@ -170,11 +170,8 @@ class SyntheticCocoDetection(torch.utils.data.Dataset):
         return img, target, blur_dict
 
     def annotations(self, idx):
-        """The target of item idx without rendering the image or running the transforms (same generator
-        stream: the image's 3*H*W draws are skipped by drawing them)."""
-        g = torch.Generator().manual_seed(self.seed + idx)
-        torch.rand(3, self.size[0], self.size[1], generator=g)
-        return self._target(idx, g)
+        """The target of item idx without rendering the image or running the transforms (same generator stream)."""
+        return self._target(idx, torch.Generator().manual_seed(self.seed + idx))
 
 
 def convert_to_coco_api(ds):

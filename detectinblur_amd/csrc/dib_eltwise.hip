@@ -7,9 +7,12 @@
 
 namespace dib {
 
-template <bool RES, bool RELU>
+// MASK: also write the ReLU's sign pattern, one byte per float4 (bits 0-3 = element > 0): what the backward pass needs of
+// the output, at 1/16 of its size (the backward then reads 4.25 instead of 8 bytes per element).
+template <bool RES, bool RELU, bool MASK>
 __global__ __launch_bounds__(256) void bias_act_vec4_kernel(float4 *__restrict__ x, const float4 *__restrict__ bias,
-                                                           const float4 *__restrict__ res, long long n4, int C4) {
+                                                           const float4 *__restrict__ res, long long n4, int C4,
+                                                           unsigned char *__restrict__ mask) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 v = x[i];
     const float4 b = bias[(int)(i % C4)];
@@ -17,6 +20,18 @@ __global__ __launch_bounds__(256) void bias_act_vec4_kernel(float4 *__restrict__
     if (RES) { const float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
     if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     x[i] = v;
+    if (MASK) mask[i] = (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
+  }
+}
+
+// ReLU backward from that mask: out = mask ? grad : 0 (torch's threshold_backward(grad, y, 0) with y > 0 read from the mask).
+__global__ __launch_bounds__(256) void relu_mask_bwd_kernel(const float4 *__restrict__ g, const unsigned char *__restrict__ mask,
+                                                           float4 *__restrict__ out, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = g[i];
+    const unsigned m = mask[i];
+    v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+    out[i] = v;
   }
 }
 
@@ -37,8 +52,44 @@ using namespace dib;
 
 // x_dev: [n_elems] fp32 viewed as [..., C] with the channel fastest (NHWC storage), updated in place:
 //   x = act(x + bias[c] (+ residual)),  act = ReLU when relu != 0.
+static int bias_act_impl(float *x_dev, const float *bias_dev, const float *residual_dev, long long n_elems, int C, int relu,
+                         unsigned char *mask_dev, void *stream);
+
 extern "C" int dib_bias_act_nhwc(float *x_dev, const float *bias_dev, const float *residual_dev, long long n_elems, int C,
                                  int relu, void *stream) {
+  return bias_act_impl(x_dev, bias_dev, residual_dev, n_elems, C, relu, nullptr, stream);
+}
+
+// Same, and mask_dev[n_elems / 4] receives the sign pattern of the result (one byte per 4 consecutive elements, bit k =
+// element 4i + k > 0): dib_relu_mask_backward's input.  Needs C % 4 == 0 and 16-byte aligned pointers.
+extern "C" int dib_bias_act_mask_nhwc(float *x_dev, const float *bias_dev, const float *residual_dev, long long n_elems, int C,
+                                      unsigned char *mask_dev, void *stream) {
+  if (!mask_dev) { set_error("dib_bias_act_mask_nhwc: null mask pointer"); return DIB_EINVAL; }
+  if ((C % 4) != 0 || (((uintptr_t)x_dev | (uintptr_t)bias_dev | (uintptr_t)residual_dev) & 15) != 0) {
+    set_error("dib_bias_act_mask_nhwc: needs C %% 4 == 0 and 16-byte aligned tensors");
+    return DIB_EINVAL;
+  }
+  return bias_act_impl(x_dev, bias_dev, residual_dev, n_elems, C, 1, mask_dev, stream);
+}
+
+// grad_out = mask ? grad_in : 0 over n_elems fp32 values (n_elems % 4 == 0, 16-byte aligned; grad_out may alias grad_in).
+extern "C" int dib_relu_mask_backward(const float *grad_in_dev, const unsigned char *mask_dev, float *grad_out_dev, long long n_elems,
+                                      void *stream) {
+  if (n_elems < 0 || (n_elems % 4) != 0) { set_error("dib_relu_mask_backward: n_elems must be a non-negative multiple of 4"); return DIB_EINVAL; }
+  if (n_elems == 0) return DIB_OK;
+  if (!grad_in_dev || !mask_dev || !grad_out_dev) { set_error("dib_relu_mask_backward: null pointer"); return DIB_EINVAL; }
+  if ((((uintptr_t)grad_in_dev | (uintptr_t)grad_out_dev) & 15) != 0) { set_error("dib_relu_mask_backward: tensors must be 16-byte aligned"); return DIB_EINVAL; }
+  const long long n4 = n_elems / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)grad_in_dev, mask_dev,
+                     (float4 *)grad_out_dev, n4);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
+
+static int bias_act_impl(float *x_dev, const float *bias_dev, const float *residual_dev, long long n_elems, int C, int relu,
+                         unsigned char *mask_dev, void *stream) {
   if (n_elems < 0 || C <= 0 || (n_elems % C) != 0) { set_error("dib_bias_act_nhwc: n_elems must be a multiple of C"); return DIB_EINVAL; }
   if (n_elems == 0) return DIB_OK;
   if (!x_dev || !bias_dev) { set_error("dib_bias_act_nhwc: null pointer"); return DIB_EINVAL; }
@@ -49,8 +100,10 @@ extern "C" int dib_bias_act_nhwc(float *x_dev, const float *bias_dev, const floa
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride: 32 workgroups per CU
 #define DIB_LAUNCH(RES, RELU)                                                                                         \
   do {                                                                                                                \
-    if (vec) hipLaunchKernelGGL((bias_act_vec4_kernel<RES, RELU>), dim3((unsigned)blocks), dim3(256), 0, s, (float4 *)x_dev, \
-                                (const float4 *)bias_dev, (const float4 *)residual_dev, n, C / 4);                    \
+    if (vec && mask_dev) hipLaunchKernelGGL((bias_act_vec4_kernel<RES, true, true>), dim3((unsigned)blocks), dim3(256), 0, s,        \
+                                (float4 *)x_dev, (const float4 *)bias_dev, (const float4 *)residual_dev, n, C / 4, mask_dev); \
+    else if (vec) hipLaunchKernelGGL((bias_act_vec4_kernel<RES, RELU, false>), dim3((unsigned)blocks), dim3(256), 0, s, (float4 *)x_dev, \
+                                (const float4 *)bias_dev, (const float4 *)residual_dev, n, C / 4, (unsigned char *)nullptr); \
     else hipLaunchKernelGGL((bias_act_scalar_kernel<RES, RELU>), dim3((unsigned)blocks), dim3(256), 0, s, x_dev, bias_dev,   \
                             residual_dev, n, C);                                                                      \
   } while (0)

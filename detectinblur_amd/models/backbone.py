@@ -47,24 +47,44 @@ FOLD_FROZEN_BN = True
 
 class _BiasAct(torch.autograd.Function):
     """x = act(x + bias[c] (+ residual)) in place on a channels-last fp32 CUDA tensor, one HIP launch
-    (include/dib.h: dib_bias_act_nhwc).  Backward: ReLU mask from the saved output (one stock pass);
+    (include/dib.h: dib_bias_act_nhwc / dib_bias_act_mask_nhwc).  With ReLU the forward also writes the output's sign
+    pattern (one byte per 4 elements) and the backward is one HIP pass over the gradient and that mask
+    (dib_relu_mask_backward: 8.25 bytes per element where torch's threshold_backward on the saved output moves 12);
     the same gradient flows to x and to the residual; the bias gradient is a channel sum when asked for."""
 
     @staticmethod
     def forward(ctx, x, bias, residual, relu):
         from .. import _lib
         N, C, H, W = x.shape
-        _lib.check(_lib.lib().dib_bias_act_nhwc(x.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
-                                                x.numel(), C, int(relu), torch.cuda.current_stream().cuda_stream))
+        stream = torch.cuda.current_stream().cuda_stream
+        res = residual.data_ptr() if residual is not None else None
+        ctx.relu, ctx.has_res, ctx.masked = bool(relu), residual is not None, False
+        if relu and C % 4 == 0 and not ((x.data_ptr() | bias.data_ptr() | (res or 0)) & 15):
+            mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=x.device)
+            _lib.check(_lib.lib().dib_bias_act_mask_nhwc(x.data_ptr(), bias.data_ptr(), res, x.numel(), C, mask.data_ptr(), stream))
+            ctx.masked = True
+            ctx.save_for_backward(mask)
+        else:
+            _lib.check(_lib.lib().dib_bias_act_nhwc(x.data_ptr(), bias.data_ptr(), res, x.numel(), C, int(relu), stream))
+            if relu:
+                ctx.save_for_backward(x)
         ctx.mark_dirty(x)
-        ctx.relu, ctx.has_res = bool(relu), residual is not None
-        if relu:
-            ctx.save_for_backward(x)
         return x
 
     @staticmethod
     def backward(ctx, grad):
-        if ctx.relu:
+        if ctx.masked:
+            from .. import _lib
+            (mask,) = ctx.saved_tensors
+            if not grad.is_contiguous(memory_format=torch.channels_last):
+                grad = grad.contiguous(memory_format=torch.channels_last)      # the mask is in NHWC element order
+            if grad.data_ptr() & 15:
+                grad = grad.clone(memory_format=torch.channels_last)
+            out = torch.empty_like(grad)     # not in place: autograd may hand the same gradient tensor to another node
+            _lib.check(_lib.lib().dib_relu_mask_backward(grad.data_ptr(), mask.data_ptr(), out.data_ptr(), grad.numel(),
+                                                         torch.cuda.current_stream().cuda_stream))
+            grad = out
+        elif ctx.relu:
             (y,) = ctx.saved_tensors
             grad = torch.ops.aten.threshold_backward(grad, y, 0)
         gb = grad.sum(dim=(0, 2, 3)) if ctx.needs_input_grad[1] else None

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 3 /* 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -186,6 +186,16 @@ int dib_coco_box_iou(const double *dt_dev, const double *gt_dev, const unsigned 
  * ------------------------------------------------------------------------------------- */
 int dib_bias_act_nhwc(float *x_dev, const float *bias_dev, const float *residual_dev, long long n_elems,
                       int C, int relu, void *stream);
+
+/* The ReLU form of the above that also leaves what its backward pass needs of the result: mask_dev[n_elems / 4],
+ * one byte per 4 consecutive elements, bit k = element 4 i + k is positive (C % 4 == 0, 16-byte aligned tensors).
+ * dib_relu_mask_backward: grad_out = mask ? grad_in : 0 -- torch's threshold_backward(grad, y, 0) (the ReLU backward
+ * behind every trunk convolution, reference models/faster_rcnn.py:367 / torchvision Bottleneck) at 8.25 instead of
+ * 12 bytes per element; grad_out may alias grad_in. */
+int dib_bias_act_mask_nhwc(float *x_dev, const float *bias_dev, const float *residual_dev, long long n_elems,
+                           int C, unsigned char *mask_dev, void *stream);
+int dib_relu_mask_backward(const float *grad_in_dev, const unsigned char *mask_dev, float *grad_out_dev,
+                           long long n_elems, void *stream);
 
 #ifdef __cplusplus
 }

@@ -292,6 +292,35 @@ def test_fused_conv_epilogue_matches_eager_ops():
 
 
 @pytest.mark.gpu
+def test_relu_mask_backward_equals_threshold_backward():
+    """The mask written by the fused epilogue (one byte per 4 elements) reproduces torch's ReLU backward bit for bit, for
+    channels-last and for planar incoming gradients, with and without a residual; exact zeros carry no gradient."""
+    from detectinblur_amd.models import backbone as B
+    torch.manual_seed(3)
+    for res in (False, True):
+        t = torch.randn(3, 64, 37, 53, device="cuda").contiguous(memory_format=torch.channels_last)
+        t[0, :, 5, 7] = 0.0                                     # exact zeros after the bias below (bias 0 on those channels)
+        bias = torch.randn(64, device="cuda")
+        bias[::2] = 0.0
+        r = torch.randn_like(t) if res else None
+        want = torch.relu(t + bias.reshape(1, -1, 1, 1) + (r if res else 0))
+        for planar_grad in (False, True):
+            a = t.clone().requires_grad_(True)
+            rr = r.clone().requires_grad_(True) if res else None
+            y = B.bias_act(a * 1.0, bias, rr, relu=True)
+            assert torch.equal(y.detach(), want)
+            g = torch.randn(3, 64, 37, 53, device="cuda")
+            if not planar_grad:
+                g = g.contiguous(memory_format=torch.channels_last)
+            y.backward(g)
+            ref = torch.ops.aten.threshold_backward(g, want, 0)
+            assert torch.equal(a.grad, ref)
+            if res:
+                assert torch.equal(rr.grad, ref)
+    assert (want[0, ::2, 5, 7] == 0).all()
+
+
+@pytest.mark.gpu
 def test_non_finite_boxes_do_not_leave_the_feature_maps():
     """A diverged step produces NaN / inf proposals; pooling and NMS must stay inside their buffers
     (the level of such a box is clamped, its samples contribute nothing or garbage, never a fault)."""
