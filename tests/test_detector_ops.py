@@ -292,6 +292,35 @@ def test_fused_conv_epilogue_matches_eager_ops():
 
 
 @pytest.mark.gpu
+def test_small_m_1x1_convolutions_through_the_gemm_path_equal_conv2d():
+    """layer4 / top-lateral 1x1 convolutions run as F.linear on the NHWC view (hipBLASLt): same values and gradients as
+    MIOpen's convolution within fp32 summation-order noise, output still channels-last."""
+    from detectinblur_amd.models import backbone as B
+    torch.manual_seed(1)
+    conv = torch.nn.Conv2d(2048, 512, 1, bias=True).cuda()
+    x = torch.randn(8, 2048, 25, 42, device="cuda").contiguous(memory_format=torch.channels_last)
+    g = torch.randn(8, 512, 25, 42, device="cuda").contiguous(memory_format=torch.channels_last)
+    outs = {}
+    try:
+        for flag in (True, False):
+            B.LINEAR_1X1 = flag
+            xi = x.clone().requires_grad_(True)
+            conv.zero_grad()
+            y = B.conv1x1(xi, conv.weight, conv.bias, conv)
+            assert y.is_contiguous(memory_format=torch.channels_last) and y.shape == (8, 512, 25, 42)
+            y.backward(g)
+            outs[flag] = (y.detach(), xi.grad, conv.weight.grad.clone(), conv.bias.grad.clone())
+    finally:
+        B.LINEAR_1X1 = True
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))
+    # large-M shapes stay on MIOpen: identical object path, bit-identical output
+    small = torch.nn.Conv2d(64, 256, 1, bias=False).cuda()
+    xs = torch.randn(2, 64, 40, 40, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert torch.equal(B.conv1x1(xs, small.weight, None, small), torch.nn.functional.conv2d(xs, small.weight))
+
+
+@pytest.mark.gpu
 def test_relu_mask_backward_equals_threshold_backward():
     """The mask written by the fused epilogue (one byte per 4 elements) reproduces torch's ReLU backward bit for bit, for
     channels-last and for planar incoming gradients, with and without a residual; exact zeros carry no gradient."""
