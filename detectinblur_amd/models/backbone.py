@@ -59,7 +59,7 @@ class _BiasAct(torch.autograd.Function):
         stream = torch.cuda.current_stream().cuda_stream
         res = residual.data_ptr() if residual is not None else None
         ctx.relu, ctx.has_res, ctx.masked = bool(relu), residual is not None, False
-        if relu and C % 4 == 0 and not ((x.data_ptr() | bias.data_ptr() | (res or 0)) & 15):
+        if relu and RELU_MASK and C % 4 == 0 and not ((x.data_ptr() | bias.data_ptr() | (res or 0)) & 15):
             mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=x.device)
             _lib.check(_lib.lib().dib_bias_act_mask_nhwc(x.data_ptr(), bias.data_ptr(), res, x.numel(), C, mask.data_ptr(), stream))
             ctx.masked = True
@@ -107,6 +107,7 @@ def bias_act(x, bias, residual=None, relu=True):
 
 
 FUSE_EPILOGUE = True
+RELU_MASK = True          # ReLU backward from the 1-byte-per-4 sign mask (False: torch's threshold_backward on the saved output)
 
 # A 1x1 stride-1 convolution on a channels-last tensor IS a GEMM [N*H*W, Cin] x [Cin, Cout] on the same memory.  MIOpen's
 # fp32 implicit-GEMM kernels win for the large-M shapes of the trunk; for the small-M, wide-channel ones (ResNet layer4 and

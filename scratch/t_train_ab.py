@@ -1,0 +1,16 @@
+"""Same-box A/B of the detector train step (bench.py's resident train_step): LINEAR_1X1 and RELU_MASK on / off."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import bench as B
+from detectinblur_amd.models import backbone as BB
+dev = torch.device("cuda", 0)
+host = B.make_psfs_host(0)
+images, dicts, psfs, _, _ = B.make_workload(0, dev, host)
+for rnd in range(2):
+    for lin, mask in ((True, True), (False, False), (True, False), (False, True)):
+        BB.LINEAR_1X1, BB.RELU_MASK = lin, mask
+        tr, ddp, opt = B.train_step_bench(images, dicts, psfs, dev, None, 1, 1, 10, 3)   # rank 1: no flop accounting
+        print("round %d linear_1x1=%d relu_mask=%d: %.2f ms/step" % (rnd, lin, mask, tr["ms_per_step"]), flush=True)
+        del ddp, opt
+        torch.cuda.empty_cache()

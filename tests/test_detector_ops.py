@@ -346,7 +346,8 @@ def test_relu_mask_backward_equals_threshold_backward():
             assert torch.equal(a.grad, ref)
             if res:
                 assert torch.equal(rr.grad, ref)
-    assert (want[0, ::2, 5, 7] == 0).all()
+        if not res:
+            assert (want[0, ::2, 5, 7] == 0).all() and (a.grad[0, ::2, 5, 7] == 0).all()
 
 
 @pytest.mark.gpu
