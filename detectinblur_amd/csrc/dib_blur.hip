@@ -39,8 +39,8 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 constexpr int TILE_W = 256;
 constexpr int PQ = WIN_PITCH;         // LDS row pitch in 8-byte words (96)
 constexpr int TH = 32;                // tile rows
-constexpr int LROWS = TH + SEG_ROWS;  // LDS rows per window (48)
-constexpr int LDS_BYTES = LROWS * PQ * 8;  // 36,864 B: four workgroups per CU
+constexpr int LROWS = TH + SEG_ROWS;  // LDS rows per window (44)
+constexpr int LDS_BYTES = LROWS * PQ * 8;  // 33,792 B: four workgroups per CU
 static_assert(WIN_PITCH * 8 == 768, "the asm below hard-codes the LDS row pitch");
 
 // 64-bit asm operands must be scalar integers: hipcc (ROCm 7.2) aliases both lanes of a
@@ -233,7 +233,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *img_bas
 
 constexpr int NW = 4;                       // waves per workgroup
 constexpr int R = TH / NW;                  // rows per lane (8)
-constexpr int G = (LROWS + NW - 1) / NW;    // LDS rows a wave fills (12): all of them in ONE batch of loads
+constexpr int G = (LROWS + NW - 1) / NW;    // LDS rows a wave fills (11): all of them in ONE batch of loads
 
 // The window of one (tile, tap segment) as a wave sees it: what to load, and later what to write to LDS.
 struct Window {
@@ -465,7 +465,7 @@ __device__ __forceinline__ bool band_entry(int T, int x, int t, int &local) {
 // Default ("quad") shape: 128 x 32 tiles, 4 waves, eight workgroups per CU (the kernel is a closed system: a CU's slots
 // each run dispatch -> prologue -> fill -> taps -> store in sequence, so slots are what buys throughput: 3 / 4 / 8 slots
 // gave 61 / 51 / 46 us on the BASELINE batch).  A lane owns FOUR columns of FOUR rows -- lane = 32 h + j computes
-// columns {j, j+32, j+64, j+96} of rows 4h .. 4h+3 of its wave's 8 rows -- and the window is stored as 8-byte elements
+// columns {j, j+32, j+64, j+96} of rows 4h .. 4h+3 of its wave's 8 tile rows (a wave FILLS 11 of the window's 44 rows) -- and the window is stored as 8-byte elements
 // e[k] = {P[k], P[k+32] | P[k+64], P[k+96]}  (k = 0 .. 31 + SEG_COLS), so that one tap is 4 x ds_read_b64 per lane: the
 // LDS serves 256 B per clock for 8-byte reads and 128 B for 4-byte ones (MI355X_MICROARCH.md, LDS table), and the first
 // 128-wide shape of round 2 (4-byte words {P[j], P[j+64]}, 8 x ds_read_b32 per tap; scratch/blur_narrow_shape.hip) ran
@@ -720,7 +720,6 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
 __device__ unsigned long long *g_timeline;
 #define DIB_TL_SLOT (*(unsigned long long *volatile *)&g_timeline)
 constexpr int TL_WORD = QLDS_BYTES / 4;
-#else
 #endif
 
 // KC: the PSF canvas (128 or 256) as a compile-time constant -- table offsets, pads and the padding mode fold, ~50 scalar

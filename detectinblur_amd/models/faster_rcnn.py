@@ -104,7 +104,15 @@ def fasterrcnn_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pre
     backbone = resnet_fpn_backbone("resnet50", False, trainable_layers=trainable_backbone_layers)
     if trunk is not None:
         sd = torch.load(trunk, map_location="cpu", weights_only=True)
-        backbone.body.load_state_dict({k: v for k, v in sd.items() if not k.startswith("fc.")}, strict=False)
+        # strict=False only to tolerate what is known to differ (the classifier head is dropped above; frozen batch-norms
+        # carry no num_batches_tracked): anything else missing or unexpected means the file has another key layout and
+        # would leave the trunk at random weights with frozen layers
+        bad = backbone.body.load_state_dict({k: v for k, v in sd.items() if not k.startswith("fc.")}, strict=False)
+        missing = [k for k in bad.missing_keys if not k.endswith("num_batches_tracked")]
+        unexpected = [k for k in bad.unexpected_keys if not k.endswith("num_batches_tracked")]
+        if missing or unexpected:
+            raise RuntimeError("%s does not hold a torchvision ResNet-50 state dict: missing %s, unexpected %s"
+                               % (trunk, missing[:5], unexpected[:5]))
     model = FasterRCNN(backbone, num_classes, **kwargs)
     if full is not None:
         model.load_state_dict(torch.load(full, map_location="cpu", weights_only=True))

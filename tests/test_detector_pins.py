@@ -241,3 +241,13 @@ def test_evaluate_equals_the_reference_gpu(pins, arrays, monkeypatch, name):
     the crop batcher), the call into the chosen detector and what reaches the COCO evaluator, against the reference's
     own `evaluate` run on CPU on the same batches."""
     _check_eval(name, torch.device("cuda"), pins, arrays, monkeypatch, 1e-5)
+
+
+def test_a_trunk_file_with_another_key_layout_is_refused(monkeypatch):
+    """`pretrained_backbone=True` with a cached file that is not a torchvision ResNet-50 state dict must not leave the trunk
+    at random weights with frozen layers (reference models/faster_rcnn.py:367 loads through torchvision, strictly)."""
+    from detectinblur_amd.models import faster_rcnn as FR
+    monkeypatch.setattr(FR, "find_pretrained", lambda kind: "/nonexistent/%s.pth" % kind)
+    monkeypatch.setattr(FR.torch, "load", lambda *a, **k: {"backbone.stem.weight": torch.zeros(1), "fc.weight": torch.zeros(1)})
+    with pytest.raises(RuntimeError, match="does not hold a torchvision ResNet-50 state dict"):
+        FR.fasterrcnn_resnet50_fpn(num_classes=91, pretrained=False, pretrained_backbone=True)
