@@ -53,17 +53,19 @@ class _BiasAct(torch.autograd.Function):
     the same gradient flows to x and to the residual; the bias gradient is a channel sum when asked for."""
 
     @staticmethod
-    def forward(ctx, x, bias, residual, relu):
+    def forward(ctx, x, bias, residual, relu, state=None):
         from .. import _lib
         N, C, H, W = x.shape
         stream = torch.cuda.current_stream().cuda_stream
         res = residual.data_ptr() if residual is not None else None
-        ctx.relu, ctx.has_res, ctx.masked = bool(relu), residual is not None, False
+        ctx.relu, ctx.has_res, ctx.masked, ctx.state = bool(relu), residual is not None, False, state
         if relu and RELU_MASK and C % 4 == 0 and not ((x.data_ptr() | bias.data_ptr() | (res or 0)) & 15):
             mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=x.device)
             _lib.check(_lib.lib().dib_bias_act_mask_nhwc(x.data_ptr(), bias.data_ptr(), res, x.numel(), C, mask.data_ptr(), stream))
             ctx.masked = True
             ctx.save_for_backward(mask)
+            if state is not None:
+                state["mask"] = mask
         else:
             _lib.check(_lib.lib().dib_bias_act_nhwc(x.data_ptr(), bias.data_ptr(), res, x.numel(), C, int(relu), stream))
             if relu:
@@ -73,7 +75,9 @@ class _BiasAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        if ctx.masked:
+        if ctx.masked and ctx.state is not None and ctx.state.get("consumer_masks"):
+            pass        # the one consumer of this output (_BlockEntry) applied the mask while it accumulated the gradient
+        elif ctx.masked:
             from .. import _lib
             (mask,) = ctx.saved_tensors
             if not grad.is_contiguous(memory_format=torch.channels_last):
@@ -88,7 +92,7 @@ class _BiasAct(torch.autograd.Function):
             (y,) = ctx.saved_tensors
             grad = torch.ops.aten.threshold_backward(grad, y, 0)
         gb = grad.sum(dim=(0, 2, 3)) if ctx.needs_input_grad[1] else None
-        return grad, gb, (grad if ctx.has_res else None), None
+        return grad, gb, (grad if ctx.has_res else None), None, None
 
 
 def bias_act(x, bias, residual=None, relu=True):
@@ -99,7 +103,11 @@ def bias_act(x, bias, residual=None, relu=True):
             and (residual is None or (residual.shape == x.shape and residual.dtype == torch.float32
                                       and residual.is_contiguous(memory_format=torch.channels_last))))
     if fast:
-        return _BiasAct.apply(x, bias.contiguous(), residual, relu)
+        state = {} if relu else None
+        y = _BiasAct.apply(x, bias.contiguous(), residual, relu, state)
+        if state:                       # the sign mask exists: a _BlockEntry consuming y may take over the ReLU backward
+            y._dib_relu_state = state
+        return y
     y = x + bias.reshape(1, -1, 1, 1)
     if residual is not None:
         y = y + residual
@@ -123,6 +131,64 @@ def conv1x1(x, weight, bias, conv):
             and conv.in_channels * conv.out_channels >= 512 * 1024 and x.is_contiguous(memory_format=torch.channels_last)):
         return F.linear(x.permute(0, 2, 3, 1), weight.reshape(conv.out_channels, conv.in_channels), bias).permute(0, 3, 1, 2)
     return F.conv2d(x, weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+# The input of an identity-skip bottleneck feeds its first convolution AND its skip connection: autograd would add the two
+# gradients (a 12 B / element pass) and the ReLU behind that input would mask the sum in another pass (8.25 B).  _BlockEntry is
+# that first 1x1 convolution plus the skip as ONE autograd node: its backward accumulates and masks in place on the fresh data
+# gradient (dib_add_relu_mask, 12.25 B), and tells the producing _BiasAct -- whose only consumer it is inside a ResNet stage --
+# that its mask has been applied.  Values identical to the unfused graph (the mask is idempotent and linear).
+BLOCK_ENTRY = True
+
+
+class _BlockEntry(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, state, conv):
+        ctx.conv = conv
+        mask = None
+        if state is not None and state.get("mask") is not None:
+            state["consumer_masks"] = True
+            mask = state["mask"]
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(x, weight, *([mask] if mask is not None else []))
+        return conv1x1(x, weight, None, conv), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_out, g_skip):
+        from .. import _lib
+        x, weight = ctx.saved_tensors[:2]
+        mask = ctx.saved_tensors[2] if ctx.has_mask else None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not g_out.is_contiguous(memory_format=torch.channels_last):
+            g_out = g_out.contiguous(memory_format=torch.channels_last)
+        dx, dw, _ = torch.ops.aten.convolution_backward(g_out, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                        [need_x, need_w, False])
+        if need_x:
+            if not dx.is_contiguous(memory_format=torch.channels_last) or dx.data_ptr() & 15:
+                dx = dx.clone(memory_format=torch.channels_last)
+            if g_skip is not None:
+                if not g_skip.is_contiguous(memory_format=torch.channels_last) or g_skip.data_ptr() & 15:
+                    g_skip = g_skip.clone(memory_format=torch.channels_last)
+                _lib.check(_lib.lib().dib_add_relu_mask(dx.data_ptr(), g_skip.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                                        dx.numel(), torch.cuda.current_stream().cuda_stream))
+            elif mask is not None:
+                _lib.check(_lib.lib().dib_relu_mask_backward(dx.data_ptr(), mask.data_ptr(), dx.data_ptr(), dx.numel(),
+                                                             torch.cuda.current_stream().cuda_stream))
+        return (dx if need_x else None), (dw if need_w else None), None, None
+
+
+def block_entry(x, conv, bn):
+    """(relu(bn(conv(x))), x) for the first convolution of an identity-skip bottleneck, or None where the fused node does not
+    apply (CPU, planar tensors, odd channel counts, a batch-norm that is not frozen)."""
+    if not (BLOCK_ENTRY and FUSE_EPILOGUE and FOLD_FROZEN_BN and isinstance(bn, FrozenBatchNorm2d) and conv.bias is None
+            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and not (x.data_ptr() & 15) and torch.is_grad_enabled()
+            and (x.requires_grad or conv.weight.requires_grad)):
+        return None
+    scale, shift = bn.affine()
+    out, skip = _BlockEntry.apply(x, conv.weight * scale.reshape(-1, 1, 1, 1), getattr(x, "_dib_relu_state", None), conv)
+    return bias_act(out, shift, None, True), skip
 
 
 def conv_bn(x, conv, bn, relu=False, residual=None):
@@ -152,8 +218,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
-        out = conv_bn(x, self.conv1, self.bn1, relu=True)
+        entry = block_entry(x, self.conv1, self.bn1) if self.downsample is None else None
+        if entry is not None:
+            out, idt = entry
+        else:
+            idt = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
+            out = conv_bn(x, self.conv1, self.bn1, relu=True)
         out = conv_bn(out, self.conv2, self.bn2, relu=True)
         return conv_bn(out, self.conv3, self.bn3, relu=True, residual=idt)
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -196,6 +196,10 @@ int dib_bias_act_mask_nhwc(float *x_dev, const float *bias_dev, const float *res
                            int C, unsigned char *mask_dev, void *stream);
 int dib_relu_mask_backward(const float *grad_in_dev, const unsigned char *mask_dev, float *grad_out_dev,
                            long long n_elems, void *stream);
+/* Gradient accumulation at a residual block's input (torchvision Bottleneck: the block input feeds conv1 AND the skip
+ * connection, autograd adds the two gradients) fused with the ReLU backward of that input: a = (a + b), zeroed where the
+ * mask bit is clear; mask_dev NULL = plain in-place accumulate. */
+int dib_add_relu_mask(float *a_dev, const float *b_dev, const unsigned char *mask_dev, long long n_elems, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,9 +8,9 @@ dev = torch.device("cuda", 0)
 host = B.make_psfs_host(0)
 images, dicts, psfs, _, _ = B.make_workload(0, dev, host)
 for rnd in range(2):
-    for lin, mask in ((True, True), (False, False), (True, False), (False, True)):
-        BB.LINEAR_1X1, BB.RELU_MASK = lin, mask
+    for lin, mask, entry in ((True, True, True), (True, True, False), (False, False, False)):
+        BB.LINEAR_1X1, BB.RELU_MASK, BB.BLOCK_ENTRY = lin, mask, entry
         tr, ddp, opt = B.train_step_bench(images, dicts, psfs, dev, None, 1, 1, 10, 3)   # rank 1: no flop accounting
-        print("round %d linear_1x1=%d relu_mask=%d: %.2f ms/step" % (rnd, lin, mask, tr["ms_per_step"]), flush=True)
+        print("round %d linear_1x1=%d relu_mask=%d block_entry=%d: %.2f ms/step" % (rnd, lin, mask, entry, tr["ms_per_step"]), flush=True)
         del ddp, opt
         torch.cuda.empty_cache()

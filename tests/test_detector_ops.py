@@ -292,6 +292,39 @@ def test_fused_conv_epilogue_matches_eager_ops():
 
 
 @pytest.mark.gpu
+def test_block_entry_node_is_bit_identical_to_the_plain_graph():
+    """conv1 + skip of an identity bottleneck as one autograd node (gradient accumulate + ReLU mask in one pass, the
+    producer's mask pass skipped): outputs, input gradient and every weight gradient of a ResNet stage equal, bit for
+    bit, those of the graph autograd builds by itself; also with a frozen first block and with an extra consumer of the
+    stage input."""
+    from detectinblur_amd.models import backbone as B
+    torch.manual_seed(2)
+    body = B.ResNet50Body().cuda().to(memory_format=torch.channels_last)
+    for mod in body.modules():
+        if isinstance(mod, B.FrozenBatchNorm2d):
+            mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-.2, .2); mod.running_mean.uniform_(-.2, .2); mod.running_var.uniform_(0.5, 1.5)
+    x0 = torch.randn(2, 256, 40, 56, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = {}
+    try:
+        for flag in (True, False):
+            B.BLOCK_ENTRY = flag
+            for p in body.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y2 = body.layer2(x)                    # downsample block + 3 identity blocks
+            y3 = body.layer3(y2)                   # y2 has a second consumer below: its producer must still mask
+            loss = y3.square().mean() + (y2 * 0.5).sum() * 1e-3
+            loss.backward()
+            res[flag] = [y2.detach().clone(), y3.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in body.layer2.parameters()] \
+                + [p.grad.clone() for p in body.layer3.parameters()]
+    finally:
+        B.BLOCK_ENTRY = True
+    assert len(res[True]) > 20
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_small_m_1x1_convolutions_through_the_gemm_path_equal_conv2d():
     """layer4 / top-lateral 1x1 convolutions run as F.linear on the NHWC view (hipBLASLt): same values and gradients as
     MIOpen's convolution within fp32 summation-order noise, output still channels-last."""
