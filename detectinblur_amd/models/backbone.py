@@ -124,13 +124,29 @@ RELU_MASK = True          # ReLU backward from the 1-byte-per-4 sign mask (False
 LINEAR_1X1 = True
 
 
+def _as_gemm(x, conv):
+    return (LINEAR_1X1 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and x.is_cuda and x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] <= 16384
+            and conv.in_channels * conv.out_channels >= 512 * 1024 and x.is_contiguous(memory_format=torch.channels_last))
+
+
 def conv1x1(x, weight, bias, conv):
     """F.conv2d for every convolution; the same contraction through F.linear for 1x1 / stride 1 / small M / wide channels."""
-    if (LINEAR_1X1 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
-            and x.is_cuda and x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] <= 16384
-            and conv.in_channels * conv.out_channels >= 512 * 1024 and x.is_contiguous(memory_format=torch.channels_last)):
+    if _as_gemm(x, conv):
         return F.linear(x.permute(0, 2, 3, 1), weight.reshape(conv.out_channels, conv.in_channels), bias).permute(0, 3, 1, 2)
     return F.conv2d(x, weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def _conv1x1_base(x, weight, conv):
+    """conv1x1 without autograd whose result is a tensor of its own (not a view of the GEMM's output): what a custom
+    autograd node may hand to an in-place epilogue."""
+    if _as_gemm(x, conv):
+        N, _, H, W = x.shape
+        out = torch.empty((N, conv.out_channels, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        torch.mm(x.permute(0, 2, 3, 1).reshape(-1, conv.in_channels), weight.reshape(conv.out_channels, conv.in_channels).t(),
+                 out=out.permute(0, 2, 3, 1).view(-1, conv.out_channels))
+        return out
+    return F.conv2d(x, weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 # The input of an identity-skip bottleneck feeds its first convolution AND its skip connection: autograd would add the two
@@ -151,7 +167,7 @@ class _BlockEntry(torch.autograd.Function):
             mask = state["mask"]
         ctx.has_mask = mask is not None
         ctx.save_for_backward(x, weight, *([mask] if mask is not None else []))
-        return conv1x1(x, weight, None, conv), x.view_as(x)
+        return _conv1x1_base(x, weight, conv), x.view_as(x)
 
     @staticmethod
     def backward(ctx, g_out, g_skip):
