@@ -231,6 +231,27 @@ def clamp_boxes(boxes, H, W):
     _lib.check(_lib.lib().dib_clamp_boxes(boxes.data_ptr(), boxes.shape[0], H, W, _stream()))
 
 
+def post_ops(image, noise_var=None, block_scale=None):
+    """noise + clamp and / or nearest-neighbour block artefacts on one C x H x W (or H x W) CUDA image, one launch
+    (reference models/blur_functions.py:72-81).  The noise field's key is drawn from torch's HOST generator (reproducible
+    under torch.manual_seed, no device synchronisation)."""
+    _require_cuda(image, "image")
+    if image.dtype not in _DT:
+        raise TypeError("image dtype %s not supported (float16 / float32)" % image.dtype)
+    img = image if image.is_contiguous() else image.contiguous()
+    if img.dim() == 3:
+        C, H, W = img.shape
+    elif img.dim() == 2:
+        C, (H, W) = 1, img.shape
+    else:
+        raise ValueError("image must be C x H x W, got %s" % (tuple(image.shape),))
+    out = torch.empty_like(img)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item()) if noise_var is not None else 0
+    _lib.check(_lib.lib().dib_post_ops(img.data_ptr(), out.data_ptr(), C, H, W, _DT[img.dtype], float(noise_var or 0.0), seed,
+                                       float(block_scale or 0.0), _stream(img.device)))
+    return out
+
+
 def rasterize_psfs(traj, fractions, canvas=256, center=True, out_n=None, want64=True, want16=True):
     """traj: [B, iters] complex128 CUDA tensor (or anything torch.as_tensor accepts);
     fractions: B python floats.  Returns (psf64 [B,n,n] float64 | None, psf16 [B,n,n] float16 | None).

@@ -15,19 +15,32 @@ import torch
 from .. import _lib, blur_ops
 
 
+FUSE_POST_OPS = True      # False: the stock torch ops below on the GPU as well (what the fused kernel is tested against)
+
+
 def _post_ops(output, add_noise, noise_level, add_block, add_jpeg_artifact, jpeg_compressor):
-    # reference models/blur_functions.py:72-87 -- stock torch ops, same RNG draw order
+    """reference models/blur_functions.py:72-87.  The host draws (noise variance, coin flips, scale factor, JPEG quality)
+    are the reference's, in its order on numpy's global stream.  On the GPU noise + clamp + block run as ONE HIP pass
+    (csrc/dib_postops.hip; block path bit-identical to torch's two `interpolate` calls, noise from the kernel's own
+    counter-based generator keyed by a draw from torch's host generator); CPU tensors take the stock torch ops."""
+    noise_var = block_scale = None
     if add_noise:
         noise_var = np.random.uniform(0.00000001, noise_level)
-        output = torch.clamp(output + (torch.randn_like(output) * math.sqrt(noise_var)), 0, 1)
     if add_block:
         if np.random.uniform(0, 1) > 0.5:
-            original_shape = output.shape
-            scale_factor = np.random.uniform(0.6, 1)
-            output = torch.nn.functional.interpolate(output.unsqueeze(0), scale_factor=(scale_factor, scale_factor),
-                                                     mode="nearest").squeeze()
-            output = torch.nn.functional.interpolate(output.unsqueeze(0), size=original_shape[1:],
-                                                     mode="nearest").squeeze()
+            block_scale = np.random.uniform(0.6, 1)
+    if noise_var is not None or block_scale is not None:
+        if FUSE_POST_OPS and output.is_cuda and output.dtype in blur_ops._DT and output.dim() in (2, 3):
+            output = blur_ops.post_ops(output, noise_var, block_scale)
+        else:
+            if noise_var is not None:
+                output = torch.clamp(output + (torch.randn_like(output) * math.sqrt(noise_var)), 0, 1)
+            if block_scale is not None:
+                original_shape = output.shape
+                output = torch.nn.functional.interpolate(output.unsqueeze(0), scale_factor=(block_scale, block_scale),
+                                                         mode="nearest").squeeze()
+                output = torch.nn.functional.interpolate(output.unsqueeze(0), size=original_shape[1:],
+                                                         mode="nearest").squeeze()
     if add_jpeg_artifact:
         if np.random.uniform(0, 1) > 0.35:
             quality = np.random.uniform(20, 90)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_post_ops; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -200,6 +200,19 @@ int dib_relu_mask_backward(const float *grad_in_dev, const unsigned char *mask_d
  * connection, autograd adds the two gradients) fused with the ReLU backward of that input: a = (a + b), zeroed where the
  * mask bit is clear; mask_dev NULL = plain in-place accumulate. */
 int dib_add_relu_mask(float *a_dev, const float *b_dev, const unsigned char *mask_dev, long long n_elems, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Post-blur corruption chain of manual_blur (reference models/blur_functions.py:72-81) in one pass:
+ *   noise_var > 0:    out = clamp(in + N(0, noise_var), 0, 1)                    (:72-74, --add_noise)
+ *   block_scale > 0:  out = nearest-up(nearest-down(., scale_factor = block_scale), size = original)   (:76-81, --add_block)
+ * applied in that order (the noise of a source pixel travels with it into every block copy).  The block path equals
+ * torch's two interpolate calls bit for bit; the noise field comes from a counter-based generator keyed by `seed`
+ * (same distribution and rounding steps as torch's expression, not torch's sample values).  C x H x W planes of
+ * DIB_F16 / DIB_F32; out must not alias in.  The host draws (variance, coin flip, scale factor) stay with the caller, in
+ * the reference's order on numpy's global stream.
+ * ------------------------------------------------------------------------------------- */
+int dib_post_ops(const void *in_dev, void *out_dev, int C, int H, int W, int dtype, double noise_var,
+                 unsigned long long seed, double block_scale, void *stream);
 
 #ifdef __cplusplus
 }
