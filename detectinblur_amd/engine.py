@@ -7,7 +7,7 @@ What one training step does, in order (reference engine.py:74-158):
   over RCCL overlapped with it) -> SGD step -> warm-up LR step.
 Differences from the reference are confined to mechanics: images cross PCIe as the loader's pinned fp32 and
 are converted to Half on the device (same round-to-nearest-even as `.half()` on the host), the blur needs no
-host synchronisation, and the logged loss is fetched with one `.item()` per step.
+host synchronisation, and the logged losses reach the host through pinned memory without draining the stream.
 `evaluate` returns the reference's `CocoEvaluator` surface (`.coco_eval["bbox"].stats`) computed by the
 in-repo `coco_eval.py` (no pycocotools), see EvaluationResult.
 """
@@ -148,6 +148,7 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
 
         loss_dict_reduced = utils.reduce_dict(loss_dict)                 # logging only
         losses_reduced = sum(loss for loss in loss_dict_reduced.values())
+        logged = _to_host_async(losses_reduced, loss_dict_reduced)
 
         lr_before = optimizer.param_groups[0]["lr"]        # what the reference's writer logs: read ahead of the warm-up step (:142)
         optimizer.zero_grad()
@@ -155,14 +156,16 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
         optimizer.step()
         if lr_scheduler is not None:
             lr_scheduler.step()
-        # Logging and the finite-loss check read the PREVIOUS step's numbers: those are on the host already, so the
-        # `.item()` never waits, and this step's forward, backward and update were all enqueued before anything is
-        # read.  (The reference reads the current loss between forward and backward, engine.py:131-148: the host then
-        # waits for the forward pass and the GPU idles while the backward pass is issued.)  A non-finite loss still
-        # stops the run, one step later; the last step is checked behind the loop.
+        # Logging and the finite-loss check read the PREVIOUS step's numbers, which `_to_host_async` sent to pinned host
+        # memory right behind that step's forward pass: reading them waits for that copy's event only, long complete, and
+        # this step's forward, backward and update are all enqueued already.  (The reference reads the current loss
+        # between forward and backward, engine.py:131-148: the host waits for the forward pass and the GPU idles while
+        # the backward pass is issued.  A plain `.item()` here would be no better: its copy queues up behind everything
+        # enqueued so far and drains the stream once per step -- 3-4 ms of idle GPU until the next step's first kernels.)
+        # A non-finite loss still stops the run, one step later; the last step is checked behind the loop.
         if deferred is not None:
             _log_step(*deferred)
-        deferred = (metric_logger, writer, losses_reduced, loss_dict_reduced, lr_before, optimizer.param_groups[0]["lr"],
+        deferred = (metric_logger, writer, logged, lr_before, optimizer.param_groups[0]["lr"],
                     iteration_count, epoch, len(data_loader), print_freq)
         # reference :160-162, literally: `early_stop=False` (the signature's default) compares as 0 and ends the epoch
         # after two iterations; train.py passes --early_stop (None unless given).  The iteration that breaks is
@@ -177,11 +180,27 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
     return metric_logger
 
 
-def _log_step(metric_logger, writer, losses_reduced, loss_dict_reduced, lr_before, lr_after, iteration_count, epoch, n_iter,
-              print_freq, update_meters=True):
+def _to_host_async(total, loss_dict):
+    """(keys, values on the host, event): the scalars of one step on their way to pinned memory, no stream drain."""
+    keys = list(loss_dict.keys())
+    vals = torch.stack([total.detach()] + [loss_dict[k].detach() for k in keys]).float()
+    if not vals.is_cuda:
+        return keys, vals, None
+    host = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
+    host.copy_(vals, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    return keys, host, done
+
+
+def _log_step(metric_logger, writer, logged, lr_before, lr_after, iteration_count, epoch, n_iter, print_freq, update_meters=True):
     """reference engine.py:131-158: TensorBoard scalars every 500 iterations (learning rate as it was BEFORE this
     iteration's warm-up step), exit on a non-finite loss, meters (learning rate AFTER the step)."""
-    loss_value = losses_reduced.item()
+    keys, host, done = logged
+    if done is not None:
+        done.synchronize()
+    values = host.tolist()
+    loss_value, loss_dict_reduced = values[0], dict(zip(keys, values[1:]))
     if iteration_count % 500 == 0 and writer is not None and utils.is_main_process() and iteration_count % print_freq == 0:
         step = iteration_count + epoch * n_iter
         for key, v in loss_dict_reduced.items():
@@ -193,7 +212,7 @@ def _log_step(metric_logger, writer, losses_reduced, loss_dict_reduced, lr_befor
         print(loss_dict_reduced)
         sys.exit(1)
     if update_meters:
-        metric_logger.update(loss=losses_reduced, **loss_dict_reduced)
+        metric_logger.update(loss=loss_value, **loss_dict_reduced)
         metric_logger.update(lr=lr_after)
 
 
