@@ -252,6 +252,25 @@ def post_ops(image, noise_var=None, block_scale=None):
     return out
 
 
+def jpeg_roundtrip(image, q_luma, q_chroma):
+    """One 3 x H x W CUDA image in [0, 1] (float16 / float32) through the JPEG round trip in one launch; q_luma / q_chroma:
+    the 8 x 8 tables times the quality factor (anything numpy reads).  Returns a float16 CUDA tensor of the same shape
+    (reference transforms.py:467-493 + models/jpeg/DiffJPEG.py)."""
+    import ctypes
+    import numpy as np
+    _require_cuda(image, "image")
+    if image.dtype not in _DT or image.dim() != 3 or image.shape[0] != 3:
+        raise ValueError("jpeg_roundtrip needs a 3 x H x W float16 / float32 CUDA image")
+    img = image if image.is_contiguous() else image.contiguous()
+    out = torch.empty(img.shape, dtype=torch.float16, device=img.device)
+    fp = ctypes.POINTER(ctypes.c_float)
+    qy = np.ascontiguousarray(np.asarray(q_luma, dtype=np.float32).reshape(64))
+    qc = np.ascontiguousarray(np.asarray(q_chroma, dtype=np.float32).reshape(64))
+    _lib.check(_lib.lib().dib_jpeg_roundtrip(img.data_ptr(), out.data_ptr(), int(img.shape[1]), int(img.shape[2]), _DT[img.dtype],
+                                             qy.ctypes.data_as(fp), qc.ctypes.data_as(fp), _stream(img.device)))
+    return out
+
+
 def rasterize_psfs(traj, fractions, canvas=256, center=True, out_n=None, want64=True, want16=True):
     """traj: [B, iters] complex128 CUDA tensor (or anything torch.as_tensor accepts);
     fractions: B python floats.  Returns (psf64 [B,n,n] float64 | None, psf16 [B,n,n] float16 | None).

@@ -263,9 +263,25 @@ class BlurImage(object):
         return output_image, target, blur_dict
 
 
+FUSE_JPEG = True      # False: the module-by-module torch path on the GPU as well (what the fused kernel is tested against)
+
+
 def add_jpeg_artifact_to_image(image_GPU, jpeg_compressor, quality):
-    """Reflect-pad to a multiple of 16, run the (external) DiffJPEG module, crop back.
-    Reference transforms.py:467-493.  The compressor itself (models/jpeg) is out of scope."""
+    """Reflect-pad to a multiple of 16, JPEG round trip at `quality`, crop back; returns a Half tensor on the HOST, as the
+    reference does (transforms.py:467-493).  A CUDA image and this package's non-differentiable `DiffJPEG` take one HIP
+    launch (csrc/dib_jpeg.hip); anything else runs the module."""
+    from .models.jpeg import DiffJPEG
+    if (FUSE_JPEG and image_GPU.is_cuda and image_GPU.dim() == 3 and image_GPU.shape[0] == 3 and type(jpeg_compressor) is DiffJPEG
+            and jpeg_compressor.rounding is torch.round and image_GPU.dtype in (torch.float16, torch.float32)):
+        from . import blur_ops
+        jpeg_compressor.setQuality(quality)
+        f = np.float32(jpeg_compressor.factor)
+        tables = jpeg_compressor.__dict__.get("_tables_host")
+        if tables is None:        # host copies of the two 8 x 8 tables, once per module (its buffers live on the device)
+            tables = jpeg_compressor.__dict__["_tables_host"] = (jpeg_compressor.luma.detach().cpu().numpy().copy(),
+                                                                 jpeg_compressor.chroma.detach().cpu().numpy().copy())
+        out = blur_ops.jpeg_roundtrip(image_GPU, tables[0] * f, tables[1] * f)
+        return out.cpu().detach().squeeze()
     image_GPU = image_GPU.unsqueeze(0)
     w, h = image_GPU.shape[3], image_GPU.shape[2]
     wp, hp = 16 - w % 16, 16 - h % 16

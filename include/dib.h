@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_post_ops; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -213,6 +213,15 @@ int dib_add_relu_mask(float *a_dev, const float *b_dev, const unsigned char *mas
  * ------------------------------------------------------------------------------------- */
 int dib_post_ops(const void *in_dev, void *out_dev, int C, int H, int W, int dtype, double noise_var,
                  unsigned long long seed, double block_scale, void *stream);
+
+/* JPEG round trip of one image in one launch (reference transforms.py:467-493 around models/jpeg/DiffJPEG.py:
+ * reflect-pad to a multiple of 16, RGB -> YCbCr 4:2:0 -> 8x8 DCT -> quantise with table x factor -> back -> crop).
+ * in_dev: 3 x H x W planes of DIB_F16 / DIB_F32 in [0, 1]; out_dev: 3 x H x W planes of fp16 (the reference returns
+ * `.half()`); q_luma / q_chroma: HOST pointers to the 8 x 8 tables already multiplied by the quality factor, row-major
+ * [u][v].  fp32 arithmetic as the reference's; the DCT sums run in this kernel's order: results within one
+ * quantisation step of the reference's (tests/test_jpeg.py), as torch's own GPU path is. */
+int dib_jpeg_roundtrip(const void *in_dev, void *out_dev, int H, int W, int dtype, const float *q_luma,
+                       const float *q_chroma, void *stream);
 
 #ifdef __cplusplus
 }
