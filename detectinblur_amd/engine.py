@@ -12,6 +12,7 @@ host synchronisation, and the logged losses reach the host through pinned memory
 in-repo `coco_eval.py` (no pycocotools), see EvaluationResult.
 """
 import math
+import os
 import sys
 import time
 
@@ -90,6 +91,19 @@ def _stage(images_CPU, targets, blur_dicts, device, blurring, want_tables, cuda)
             scal = scal.pin_memory().to(device, non_blocking=True)
         thetas, l1, l2 = scal[0], scal[1], scal[2]
     return images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables
+
+
+def _estimate(blur_estimator, x, graphed):
+    """The blur estimator's logits; on a GPU through a HIP graph per input shape (a clone: the graph's output buffer is
+    overwritten by the next replay)."""
+    if not graphed:
+        return blur_estimator(x)
+    core = getattr(blur_estimator, "module", blur_estimator)
+    cache = core.__dict__.get("_dib_graphs")
+    if cache is None:
+        from .graphs import GraphCache
+        cache = core.__dict__["_dib_graphs"] = GraphCache(blur_estimator)
+    return cache(x).clone()
 
 
 def _tables_128(tables):
@@ -290,6 +304,12 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
     n_threads = torch.get_num_threads()
     torch.set_num_threads(1)
     batcher = None
+    # batch size 1 is launch-bound: the detectors' static trunk and the estimator replay as HIP graphs (graphs.py)
+    graphed = device.type == "cuda" and not os.environ.get("DIB_NO_GRAPHS")
+    for m in (ensemble_models if use_ensemble else [model]):
+        core = getattr(m, "module", m)
+        if hasattr(core, "graph_inference"):
+            core.graph_inference = graphed
     if use_ensemble:
         for m in ensemble_models:
             m.eval()
@@ -337,7 +357,7 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                 k = get_network_index_to_use_oracle(blur_dicts, idx)
             else:
                 batched, _ = batcher(images_GPU, None)
-                est = blur_estimator(batched.tensors)
+                est = _estimate(blur_estimator, batched.tensors, graphed)
                 k = (get_network_index_to_use_blur_estimator_LEHE if LEHE else get_network_index_to_use_blur_estimator)(est, idx)
             model = ensemble_models[k]
             routes.append(k)

@@ -96,6 +96,26 @@ class RegionProposalNetwork(nn.Module):
         return d["training"] if self.training else d["testing"]
 
     def filter_proposals(self, proposals, objectness, image_sizes, counts, padded=False):
+        sizes = torch.tensor([[float(s[1]), float(s[0])] for s in image_sizes], dtype=proposals.dtype)   # (w, h) per image
+        if proposals.is_cuda:
+            sizes = sizes.pin_memory().to(proposals.device, non_blocking=True)
+        boxes, scores, count = self._filter(proposals, objectness, sizes, counts)
+        if padded:
+            # training: fixed [N, post, 4] + validity mask, no host synchronisation at all (rows past
+            # the kept count repeat the image's best box and are masked by every consumer)
+            ok = torch.arange(boxes.shape[1], device=boxes.device)[None, :] < count[:, None]
+            return (boxes, ok), scores
+        return self.unpad(boxes, scores, count)
+
+    @staticmethod
+    def unpad(boxes, scores, count):
+        counts_host = count.tolist()        # the one synchronisation point
+        return [boxes[i, :c] for i, c in enumerate(counts_host)], [scores[i, :c] for i, c in enumerate(counts_host)]
+
+    def _filter(self, proposals, objectness, sizes, counts):
+        """Per-level top-k, clip, sort, NMS across levels, top post-NMS: fixed shapes, no host synchronisation (what a HIP
+        graph can hold).  sizes: [N, 2] (w, h) on the proposals' device.  Returns boxes [N, post, 4], scores [N, post] and
+        the number of rows that are real, per image."""
         N = proposals.shape[0]
         objectness = objectness.detach().reshape(N, -1)
         levels = torch.cat([torch.full((n,), i, dtype=torch.int64, device=proposals.device) for i, n in enumerate(counts)])
@@ -112,9 +132,6 @@ class RegionProposalNetwork(nn.Module):
         # before the NMS: boxes that torchvision would drop as too small are flagged invalid instead
         # (they are never kept and never suppress).  One host sync per batch (the kept counts) instead
         # of two per image, ~15 launches instead of ~20 per image.
-        sizes = torch.tensor([[float(s[1]), float(s[0])] for s in image_sizes], dtype=proposals.dtype)   # (w, h) per image
-        if proposals.is_cuda:
-            sizes = sizes.pin_memory().to(proposals.device, non_blocking=True)
         x = proposals[..., 0::2].clamp(min=0).minimum(sizes[:, None, 0:1])
         y = proposals[..., 1::2].clamp(min=0).minimum(sizes[:, None, 1:2])
         boxes = torch.stack((x[..., 0], y[..., 0], x[..., 1], y[..., 1]), dim=-1)                        # clip_boxes_to_image
@@ -130,15 +147,16 @@ class RegionProposalNetwork(nn.Module):
         keep = keep[:, :post]
         boxes = boxes.gather(1, keep[..., None].expand(-1, -1, 4))
         scores = scores.gather(1, keep)
-        if padded:
-            # training: fixed [N, post, 4] + validity mask, no host synchronisation at all (rows past
-            # the kept count repeat the image's best box and are masked by every consumer)
-            ok = torch.arange(keep.shape[1], device=keep.device)[None, :] < count.clamp(max=post)[:, None]
-            return (boxes, ok), scores
-        counts_host = count.clamp(max=post).tolist()        # the one synchronisation point
-        boxes_out = [boxes[i, :c] for i, c in enumerate(counts_host)]
-        scores_out = [scores[i, :c] for i, c in enumerate(counts_host)]
-        return boxes_out, scores_out
+        return boxes, scores, count.clamp(max=post)
+
+    def propose_static(self, feats, anchors, sizes):
+        """head + decoding + `_filter` on a list of feature maps: the sync-free part of `forward` in inference."""
+        logits, deltas = self.head(feats)
+        counts = [l[0].numel() for l in logits]
+        objectness, deltas = _flatten_levels(logits, deltas)
+        N = feats[0].shape[0]
+        proposals = self.box_coder.decode(deltas.detach(), torch.cat([anchors] * N)).view(N, -1, 4)
+        return self._filter(proposals, objectness, sizes, counts)
 
     def assign_targets(self, anchors, targets):
         labels, matched = [], []

@@ -132,3 +132,28 @@ def test_degenerate_boxes_raise_on_the_gpu_without_draining_the_queue():
         m(imgs, [good, bad], newMeans=means, newSTDs=stds)
     losses = m(imgs, [good, good], newMeans=means, newSTDs=stds)          # and the flag is clean again on the next call
     assert all(torch.isfinite(v) for v in losses.values())
+
+
+def test_graphed_inference_equals_eager_inference():
+    """engine.evaluate runs the detector's static trunk (backbone + FPN + RPN head + proposal filtering) as a HIP graph per
+    input shape: the recorded launches of the eager code, so the detections are those of the eager forward pass (to the
+    ~1e-6 by which two eager passes differ: MIOpen's kernel choice varies between calls), for two shapes, repeated
+    replays and changing image sizes inside one padded shape."""
+    m = _model().eval()
+    torch.manual_seed(1)
+    batches = [[torch.rand(3, 150, 210, device="cuda")], [torch.rand(3, 150, 210, device="cuda")], [torch.rand(3, 140, 200, device="cuda")],
+               [torch.rand(3, 120, 224, device="cuda"), torch.rand(3, 150, 190, device="cuda")], [torch.rand(3, 150, 210, device="cuda")]]
+    means = lambda n: np.tile([0.485, 0.456, 0.406], (n, 1))          # noqa: E731
+    stds = lambda n: np.tile([0.229, 0.224, 0.225], (n, 1))           # noqa: E731
+    with torch.no_grad():
+        eager = [m(list(b), newMeans=means(len(b)), newSTDs=stds(len(b))) for b in batches]
+        m.graph_inference = True
+        graphed = [m(list(b), newMeans=means(len(b)), newSTDs=stds(len(b))) for b in batches]
+        again = [m(list(b), newMeans=means(len(b)), newSTDs=stds(len(b))) for b in batches]
+    assert len(m._trunk_graphs.graphs) == 2 and all(g is not None for g in m._trunk_graphs.graphs.values())     # captured, not eager
+    for e, g, a in zip(eager, graphed, again):
+        for de, dg, da in zip(e, g, a):
+            assert dg["boxes"].shape == de["boxes"].shape and torch.equal(dg["labels"], de["labels"])
+            assert torch.allclose(dg["boxes"], de["boxes"], atol=1e-3) and torch.allclose(dg["scores"], de["scores"], atol=1e-5)
+            assert torch.equal(dg["boxes"], da["boxes"]) and torch.equal(dg["scores"], da["scores"])       # replays are deterministic
+    assert len(eager[0][0]["boxes"]) > 0
