@@ -96,9 +96,9 @@ def _stage(images_CPU, targets, blur_dicts, device, blurring, want_tables, cuda)
 def _estimate(blur_estimator, x, graphed):
     """The blur estimator's logits; on a GPU through a HIP graph per input shape (a clone: the graph's output buffer is
     overwritten by the next replay)."""
-    if not graphed:
-        return blur_estimator(x)
     core = getattr(blur_estimator, "module", blur_estimator)
+    if not graphed or not getattr(core, "graph_safe", False):      # a module that does not say so may synchronise in forward
+        return blur_estimator(x)
     cache = core.__dict__.get("_dib_graphs")
     if cache is None:
         from .graphs import GraphCache
@@ -323,6 +323,18 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
     coco_evaluator = CocoEvaluator(coco, ["bbox"], device=device if device.type == "cuda" else None)
     detections, gt_boxes, routes = {}, {}, []
     count = faulty_boxes = total_boxes = 0
+    # On a GPU the per-image COCO matching (host, ~2 ms) runs on ONE worker thread, in submission order, while the main
+    # thread waits for the next image's detector: the ground-truth boxes of an image are written before its update is
+    # submitted, and different images touch different annotations.  `evaluator_time` then measures the hand-over.
+    scorer, pending = None, []
+    if device.type == "cuda" and not os.environ.get("DIB_NO_GRAPHS"):
+        from concurrent.futures import ThreadPoolExecutor
+        scorer = ThreadPoolExecutor(max_workers=1)
+        score_stream = torch.cuda.Stream(device=device)
+
+        def score(res):           # the box-IoU kernel of the matching on its own stream: never queued behind the detector
+            with torch.cuda.stream(score_stream):
+                coco_evaluator.update(res)
     for images_CPU, targets_CPU, blur_dicts in metric_logger.log_every(data_loader, 100, "Test:"):
         if device.type == "cuda":
             torch.cuda.synchronize()
@@ -374,12 +386,19 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
             detections[image_id] = o
             gt_boxes[image_id] = utils.convert_to_xywh(t["boxes"]).cpu()
         evaluator_time = time.time()
-        coco_evaluator.update(res)                                       # reference :388-392
+        if scorer is None:
+            coco_evaluator.update(res)                                   # reference :388-392
+        else:
+            pending.append(scorer.submit(score, res))                    # scored while the GPU runs the next image
         evaluator_time = time.time() - evaluator_time
         metric_logger.update(model_time=model_time, evaluator_time=evaluator_time)
         count += 1
         if early_stop is not None and count > early_stop:
             break
+    if scorer is not None:
+        for f in pending:
+            f.result()                                                   # re-raises anything the scoring thread hit
+        scorer.shutdown()
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     print("Number of Faulty boxes: " + str(faulty_boxes) + " Total number of boxes: " + str(total_boxes))

@@ -23,6 +23,8 @@ class BasicBlock(nn.Module):
 
 
 class ResNet18(nn.Module):
+    graph_safe = True      # forward is a fixed sequence of launches: engine.evaluate may replay it as a HIP graph
+
     def __init__(self, num_classes=1000):
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
