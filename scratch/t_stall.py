@@ -11,7 +11,7 @@ from detectinblur_amd.train import _seed_worker, get_transform
 dev = torch.device("cuda", 0)
 host = B.make_psfs_host(0)
 images, dicts, psfs, _, _ = B.make_workload(0, dev, host)
-tr, ddp, opt = B.train_step_bench(images, dicts, psfs, dev, None, 1, 1, 3, 2)
+tr, ddp, opt = B.train_step_bench(images, dicts, psfs, dev, None, 1, 0, 3, 2, account=False)
 print("resident", tr["ms_per_step"], file=sys.stderr)
 with contextlib.redirect_stdout(sys.stderr):
     tf = get_transform(True, blur=True, blur_type=0.005, blur_ratio=0.75, low_exposure=True)

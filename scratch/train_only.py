@@ -7,4 +7,4 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 images, dicts, psfs, psfs_host, _ = bench.make_workload(0, dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-print(bench.train_step_bench(images, dicts, psfs, dev, None, 1, 1, n, 4)[0])      # rank 1: no flop accounting / torch profiler under rocprofv3
+print(bench.train_step_bench(images, dicts, psfs, dev, None, 1, 0, n, 4, account=False)[0])      # rank 1: no flop accounting / torch profiler under rocprofv3
