@@ -131,10 +131,30 @@ def _as_gemm(x, conv):
             and conv.in_channels * conv.out_channels >= 512 * 1024 and x.is_contiguous(memory_format=torch.channels_last))
 
 
+# MIOpen's channels-last fp32 kernels are the fast ones for the large activations of this network; for the small-M, wide 3x3
+# convolutions of ResNet layer4 (512 -> 512 at 25 x 42: M = 8,400 at b = 8) its planar kernels are 2.2x faster forward and 1.4x
+# backward (scratch/t_conv3x3_layout.py: 0.91 / 0.57 ms -> 0.41 / 0.41 ms), far more than the two 17 MB layout changes cost.
+NCHW_SMALL_3X3 = True
+
+
+def _as_planar(x, conv):
+    if not (NCHW_SMALL_3X3 and conv.kernel_size == (3, 3) and conv.groups == 1 and conv.in_channels >= 512 and x.is_cuda and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    ho = (x.shape[2] + 2 * conv.padding[0] - 3) // conv.stride[0] + 1
+    wo = (x.shape[3] + 2 * conv.padding[1] - 3) // conv.stride[1] + 1
+    return x.shape[0] * ho * wo <= 16384
+
+
 def conv1x1(x, weight, bias, conv):
-    """F.conv2d for every convolution; the same contraction through F.linear for 1x1 / stride 1 / small M / wide channels."""
+    """F.conv2d for every convolution, with two shape-based detours: the same contraction through F.linear for 1x1 / stride 1 /
+    small M / wide channels, and planar (NCHW) tensors around small-M wide 3x3 convolutions.  Output always channels-last
+    when the input is."""
     if _as_gemm(x, conv):
         return F.linear(x.permute(0, 2, 3, 1), weight.reshape(conv.out_channels, conv.in_channels), bias).permute(0, 3, 1, 2)
+    if _as_planar(x, conv):
+        y = F.conv2d(x.contiguous(), weight.contiguous(), bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return y.contiguous(memory_format=torch.channels_last)
     return F.conv2d(x, weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
