@@ -52,6 +52,26 @@ __global__ __launch_bounds__(256) void add_mask_kernel(float4 *__restrict__ a, c
   }
 }
 
+// Data gradient of a strided 1x1 convolution added into the data gradient of the stride-1 convolution that shares its input
+// (the downsample path of a ResNet stage's first block): a[n, ys * s, xs * s, :] += b[n, ys, xs, :], channels-last, in place.
+// Replaces a zero-filled full-size gradient plus a full-size add by a pass over a quarter of the pixels.
+__global__ __launch_bounds__(256) void scatter_add_kernel(float4 *__restrict__ a, const float4 *__restrict__ b, int Hs, int Ws, int C4,
+                                                         int H, int W, int s, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long p = i / C4;
+    const int xs = (int)(p % Ws);
+    p /= Ws;
+    const int ys = (int)(p % Hs);
+    const long long n = p / Hs;
+    const long long j = ((n * H + (long long)ys * s) * W + (long long)xs * s) * C4 + c;
+    float4 v = a[j];
+    const float4 w = b[i];
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    a[j] = v;
+  }
+}
+
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bias_act_scalar_kernel(float *__restrict__ x, const float *__restrict__ bias,
                                                              const float *__restrict__ res, long long n, int C) {
@@ -116,6 +136,22 @@ extern "C" int dib_add_relu_mask(float *a_dev, const float *b_dev, const unsigne
   if (blocks > 256 * 32) blocks = 256 * 32;
   if (mask_dev) hipLaunchKernelGGL(add_mask_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)a_dev, (const float4 *)b_dev, mask_dev, n4);
   else hipLaunchKernelGGL(add_mask_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)a_dev, (const float4 *)b_dev, (const unsigned char *)nullptr, n4);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
+
+// a[N, H, W, C] (channels-last fp32) += b[N, Hs, Ws, C] at the pixels (ys * stride, xs * stride); C % 4 == 0, 16-byte aligned.
+extern "C" int dib_scatter_add_nhwc(float *a_dev, const float *b_dev, int N, int H, int W, int Hs, int Ws, int C, int stride, void *stream) {
+  if (N < 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || (C % 4) != 0 || stride < 1) { set_error("dib_scatter_add_nhwc: bad shape (C %% 4 == 0)"); return DIB_EINVAL; }
+  if ((long long)(Hs - 1) * stride > H - 1 || (long long)(Ws - 1) * stride > W - 1) { set_error("dib_scatter_add_nhwc: strided grid leaves the target"); return DIB_ESHAPE; }
+  if (N == 0) return DIB_OK;
+  if (!a_dev || !b_dev) { set_error("dib_scatter_add_nhwc: null pointer"); return DIB_EINVAL; }
+  if ((((uintptr_t)a_dev | (uintptr_t)b_dev) & 15) != 0) { set_error("dib_scatter_add_nhwc: tensors must be 16-byte aligned"); return DIB_EINVAL; }
+  const long long n4 = (long long)N * Hs * Ws * (C / 4);
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)a_dev, (const float4 *)b_dev, Hs, Ws,
+                     C / 4, H, W, stride, n4);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }

@@ -214,6 +214,59 @@ class _BlockEntry(torch.autograd.Function):
         return (dx if need_x else None), (dw if need_w else None), None, None
 
 
+class _DownEntry(torch.autograd.Function):
+    """The first block of a stage: its input feeds conv1 (1x1, stride 1) and the downsample convolution (1x1, stride s).  One
+    node: the strided convolution runs densely on the gathered pixels x[:, :, ::s, ::s]; in the backward pass its data
+    gradient is added in place into conv1's (dib_scatter_add_nhwc) -- no zero-filled full-size gradient, no full-size add."""
+
+    @staticmethod
+    def forward(ctx, x, w1, wd, conv1, convd):
+        s = convd.stride[0]
+        xs = x if s == 1 else x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
+        ctx.conv1, ctx.convd, ctx.s = conv1, convd, s
+        ctx.save_for_backward(x, w1, wd, *([xs] if s != 1 else []))
+        import types
+        dense = types.SimpleNamespace(kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1,
+                                      in_channels=convd.in_channels, out_channels=convd.out_channels)
+        return _conv1x1_base(x, w1, conv1), _conv1x1_base(xs, wd, dense)
+
+    @staticmethod
+    def backward(ctx, g_a, g_d):
+        from .. import _lib
+        x, w1, wd = ctx.saved_tensors[:3]
+        xs = ctx.saved_tensors[3] if ctx.s != 1 else x
+        need_x, need_w1, need_wd = ctx.needs_input_grad[:3]
+        cl = lambda t: t if t.is_contiguous(memory_format=torch.channels_last) and not (t.data_ptr() & 15) else t.clone(memory_format=torch.channels_last)   # noqa: E731
+        args = ([1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+        dx, dw1, _ = torch.ops.aten.convolution_backward(cl(g_a), x, w1, None, *args, [need_x, need_w1, False])
+        dxs, dwd, _ = torch.ops.aten.convolution_backward(cl(g_d), xs, wd, None, *args, [need_x, need_wd, False])
+        if need_x:
+            dx, dxs = cl(dx), cl(dxs)
+            stream = torch.cuda.current_stream().cuda_stream
+            if ctx.s == 1:
+                _lib.check(_lib.lib().dib_add_relu_mask(dx.data_ptr(), dxs.data_ptr(), None, dx.numel(), stream))
+            else:
+                N, C, H, W = dx.shape
+                _lib.check(_lib.lib().dib_scatter_add_nhwc(dx.data_ptr(), dxs.data_ptr(), N, H, W, dxs.shape[2], dxs.shape[3], C, ctx.s, stream))
+        return (dx if need_x else None), (dw1 if need_w1 else None), (dwd if need_wd else None), None, None
+
+
+def down_entry(x, conv1, bn1, convd, bnd):
+    """(relu(bn1(conv1(x))), bnd(convd(x))) for the first block of a stage, or None where the fused node does not apply."""
+    if not (BLOCK_ENTRY and FUSE_EPILOGUE and FOLD_FROZEN_BN and isinstance(bn1, FrozenBatchNorm2d) and isinstance(bnd, FrozenBatchNorm2d)
+            and conv1.bias is None and convd.bias is None and conv1.kernel_size == (1, 1) and conv1.stride == (1, 1)
+            and convd.kernel_size == (1, 1) and convd.stride[0] == convd.stride[1] and convd.stride[0] in (1, 2)
+            and conv1.padding == (0, 0) and convd.padding == (0, 0) and conv1.groups == 1 and convd.groups == 1
+            and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and not (x.data_ptr() & 15) and torch.is_grad_enabled()
+            and x.requires_grad):
+        return None
+    s1, t1 = bn1.affine()
+    sd, td = bnd.affine()
+    a, d = _DownEntry.apply(x, conv1.weight * s1.reshape(-1, 1, 1, 1), convd.weight * sd.reshape(-1, 1, 1, 1), conv1, convd)
+    return bias_act(a, t1, None, True), bias_act(d, td, None, False)
+
+
 def block_entry(x, conv, bn):
     """(relu(bn(conv(x))), x) for the first convolution of an identity-skip bottleneck, or None where the fused node does not
     apply (CPU, planar tensors, odd channel counts, a batch-norm that is not frozen)."""
@@ -274,7 +327,8 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        entry = block_entry(x, self.conv1, self.bn1) if self.downsample is None else None
+        entry = (block_entry(x, self.conv1, self.bn1) if self.downsample is None
+                 else down_entry(x, self.conv1, self.bn1, self.downsample[0], self.downsample[1]))
         if entry is not None:
             out, idt = entry
         else:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -200,6 +200,11 @@ int dib_relu_mask_backward(const float *grad_in_dev, const unsigned char *mask_d
  * connection, autograd adds the two gradients) fused with the ReLU backward of that input: a = (a + b), zeroed where the
  * mask bit is clear; mask_dev NULL = plain in-place accumulate. */
 int dib_add_relu_mask(float *a_dev, const float *b_dev, const unsigned char *mask_dev, long long n_elems, void *stream);
+/* The same accumulation for the first block of a ResNet stage, whose skip is a strided 1x1 convolution: the data gradient
+ * of that convolution, computed densely on the strided pixels, is added in place into the data gradient of conv1:
+ * a[n, ys * stride, xs * stride, :] += b[n, ys, xs, :] (channels-last fp32, C % 4 == 0) -- instead of a zero-filled
+ * full-size gradient and a full-size add. */
+int dib_scatter_add_nhwc(float *a_dev, const float *b_dev, int N, int H, int W, int Hs, int Ws, int C, int stride, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Post-blur corruption chain of manual_blur (reference models/blur_functions.py:72-81) in one pass:
