@@ -125,10 +125,17 @@ RELU_MASK = True          # ReLU backward from the 1-byte-per-4 sign mask (False
 LINEAR_1X1 = True
 
 
-def _as_gemm(x, conv):
-    return (LINEAR_1X1 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
-            and x.is_cuda and x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] <= 16384
-            and conv.in_channels * conv.out_channels >= 512 * 1024 and x.is_contiguous(memory_format=torch.channels_last))
+def _as_gemm(x, conv, forward_only=False):
+    """forward_only: the caller computes the gradients itself (the entry nodes below), so the rule may follow the forward
+    direction alone: deep contractions (Cin >= 1024) also win there at M = 33,600 (1024 -> 256 at 50 x 84: 0.193 -> 0.145 ms),
+    while their data gradient is faster in MIOpen (scratch/t_conv1x1_dirs.py)."""
+    if not (LINEAR_1X1 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and x.is_cuda and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    M = x.shape[0] * x.shape[2] * x.shape[3]
+    if M <= 16384 and conv.in_channels * conv.out_channels >= 512 * 1024:
+        return True
+    return forward_only and conv.in_channels >= 1024 and M <= 65536
 
 
 # MIOpen's channels-last fp32 kernels are the fast ones for the large activations of this network; for the small-M, wide 3x3
@@ -161,7 +168,7 @@ def conv1x1(x, weight, bias, conv):
 def _conv1x1_base(x, weight, conv):
     """conv1x1 without autograd whose result is a tensor of its own (not a view of the GEMM's output): what a custom
     autograd node may hand to an in-place epilogue."""
-    if _as_gemm(x, conv):
+    if _as_gemm(x, conv, forward_only=True):
         N, _, H, W = x.shape
         out = torch.empty((N, conv.out_channels, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         torch.mm(x.permute(0, 2, 3, 1).reshape(-1, conv.in_channels), weight.reshape(conv.out_channels, conv.in_channels).t(),
@@ -296,6 +303,37 @@ def _folded(conv, bn):
     return hit[1], hit[2]
 
 
+class _WideOut1x1(torch.autograd.Function):
+    """A 1x1 stride-1 convolution with few input and many output channels (ResNet conv3: 256 -> 1024 at 50 x 84): forward and
+    weight gradient through MIOpen, the DATA gradient -- a contraction over the 1024 output channels -- as a hipBLASLt GEMM
+    on the NHWC view (0.187 -> 0.143 ms; scratch/t_conv1x1_dirs.py)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.conv2d(x, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            N, Co, H, W = g.shape
+            dx = torch.mm(g.permute(0, 2, 3, 1).reshape(-1, Co), weight.reshape(Co, -1)).view(N, H, W, -1).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw
+
+
+def _wide_out(x, conv):
+    return (LINEAR_1X1 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.out_channels >= 1024 and conv.in_channels <= 256 and x.is_cuda and x.dim() == 4 and torch.is_grad_enabled()
+            and x.requires_grad and x.is_contiguous(memory_format=torch.channels_last)
+            and 16384 < x.shape[0] * x.shape[2] * x.shape[3] <= 65536)
+
+
 def conv_bn(x, conv, bn, relu=False, residual=None):
     """conv -> frozen batch-norm (-> + residual) (-> ReLU).  With FOLD_FROZEN_BN the norm's scale goes
     into the weights and its shift into the fused epilogue."""
@@ -305,7 +343,7 @@ def conv_bn(x, conv, bn, relu=False, residual=None):
             weight = conv.weight * scale.reshape(-1, 1, 1, 1)
         else:
             weight, shift = _folded(conv, bn)
-        y = conv1x1(x, weight, None, conv)
+        y = _WideOut1x1.apply(x, weight) if _wide_out(x, conv) else conv1x1(x, weight, None, conv)
         return bias_act(y, shift, residual, relu)
     y = bn(conv(x))
     if residual is not None:
