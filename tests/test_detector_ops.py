@@ -342,6 +342,36 @@ def test_block_entry_node_equals_the_plain_graph():
 
 
 @pytest.mark.gpu
+def test_entry_nodes_with_a_partly_frozen_trunk():
+    """`trainable_backbone_layers=3` (the reference's default with pretrained weights): the stem and layer1 are frozen, so
+    the first block of layer2 sees an input that needs no gradient (plain path), the blocks behind it take the entry
+    nodes; through the whole FPN backbone, losses and every trainable gradient agree with the plain graph."""
+    from detectinblur_amd.models import backbone as B
+    torch.manual_seed(4)
+    net = B.resnet_fpn_backbone("resnet50", False, trainable_layers=3).cuda().to(memory_format=torch.channels_last)
+    for mod in net.modules():
+        if isinstance(mod, B.FrozenBatchNorm2d):
+            mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-.2, .2); mod.running_mean.uniform_(-.2, .2); mod.running_var.uniform_(0.5, 1.5)
+    assert not any(p.requires_grad for p in net.body.layer1.parameters()) and all(p.requires_grad for p in net.body.layer2.parameters())
+    x = torch.randn(2, 3, 128, 160, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = {}
+    try:
+        for flag in (True, False, True, False):
+            B.BLOCK_ENTRY = flag
+            for p in net.parameters():
+                p.grad = None
+            out = net(x)
+            loss = sum(v.square().mean() for v in out.values())
+            loss.backward()
+            res[flag] = [loss.detach()] + [p.grad.clone() for p in net.parameters() if p.requires_grad]
+    finally:
+        B.BLOCK_ENTRY = True
+    assert len(res[True]) > 60
+    for a, b in zip(res[True], res[False]):
+        assert torch.allclose(a, b, rtol=0, atol=3e-3 * float(b.abs().max()) + 1e-12)       # one flipped ReLU mask of slack
+
+
+@pytest.mark.gpu
 def test_small_m_1x1_convolutions_through_the_gemm_path_equal_conv2d():
     """layer4 / top-lateral 1x1 convolutions run as F.linear on the NHWC view (hipBLASLt): same values and gradients as
     MIOpen's convolution within fp32 summation-order noise, output still channels-last."""
