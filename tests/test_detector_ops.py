@@ -296,7 +296,8 @@ def test_block_entry_node_equals_the_plain_graph():
     """conv1 + skip of an identity bottleneck as one autograd node (gradient accumulate + ReLU mask in one pass, the
     producer's own mask pass skipped) against the graph autograd builds by itself, through a ResNet stage: at every block
     boundary the gradient the fused node delivers (already masked) equals the plain graph's gradient times the ReLU mask
-    to 1e-6 of its maximum.  Two forward passes of the same stage differ by ~1e-7 (MIOpen's kernel choice between calls),
+    to 2e-5 of its maximum (the fused node runs deep 1x1 contractions as GEMMs where the plain graph calls MIOpen).  Two forward
+    passes of the same stage differ by ~1e-6 for that reason and by MIOpen's kernel choice between calls,
     which can flip the sign of a pre-activation that is ~0: such positions (a handful) are excluded, and the final
     gradients are compared at the tolerance one flipped mask allows."""
     from detectinblur_amd.models import backbone as B
@@ -332,10 +333,10 @@ def test_block_entry_node_equals_the_plain_graph():
         flips += int((~same_mask).sum())
         want = plain[0][i] * (plain[1][i] > 0)           # the plain graph hands over the unmasked sum
         d = ((fused[0][i] - want) * same_mask).abs().max()
-        assert float(d) <= 1e-6 * float(want.abs().max()) + 1e-4 * flips * float(want.abs().max()), i
+        assert float(d) <= (2e-5 + 2e-4 * flips) * float(want.abs().max()), i      # GEMM vs MIOpen summation order; flipped masks upstream
         assert float((fused[0][i] != 0).float().mean()) < 0.8 < float((plain[0][i] != 0).float().mean())
-    assert flips < 20
-    tol = 2e-3 if flips else 1e-5
+    assert flips < 40
+    tol = 3e-3 if flips else 5e-5
     assert torch.allclose(fused[2], plain[2], rtol=0, atol=tol * float(plain[2].abs().max()))
     for a, b in zip(fused[3], plain[3]):
         assert torch.allclose(a, b, rtol=0, atol=tol * float(b.abs().max()))
