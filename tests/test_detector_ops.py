@@ -367,7 +367,7 @@ def test_entry_nodes_with_a_partly_frozen_trunk():
             res[flag] = [loss.detach()] + [p.grad.clone() for p in net.parameters() if p.requires_grad]
     finally:
         B.BLOCK_ENTRY = True
-    assert len(res[True]) > 60
+    assert len(res[True]) > 50
     for a, b in zip(res[True], res[False]):
         assert torch.allclose(a, b, rtol=0, atol=3e-3 * float(b.abs().max()) + 1e-12)       # one flipped ReLU mask of slack
 
