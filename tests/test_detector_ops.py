@@ -369,7 +369,9 @@ def test_entry_nodes_with_a_partly_frozen_trunk():
         B.BLOCK_ENTRY = True
     assert len(res[True]) > 50
     for a, b in zip(res[True], res[False]):
-        assert torch.allclose(a, b, rtol=0, atol=3e-3 * float(b.abs().max()) + 1e-12)       # one flipped ReLU mask of slack
+        # a forward pass differs from the next by ~1e-6 (kernel choice), which flips the ReLU mask of a few pre-activations
+        # that are ~0: compare in the Frobenius norm, where a handful of flipped positions weighs little
+        assert float((a - b).norm()) <= 1e-2 * float(b.norm()) + 1e-12
 
 
 @pytest.mark.gpu
