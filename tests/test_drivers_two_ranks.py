@@ -126,9 +126,9 @@ def test_evaluate_main_two_ranks_equals_one_rank(tmp_path, n):
 
 def test_evaluate_sweep_two_ranks_ensemble(tmp_path):
     """The 15-cell sweep of configs[4] (`--use_ensemble`, oracle routing, `--cpu_blur` because this host has no GPU),
-    2 ranks, 2 images per cell and rank (`--early_stop 1`): all cells complete and merge.  (No --expand_target_boxes
+    2 ranks, 1 image per cell and rank (`--early_stop 0`): all cells complete and merge.  (No --expand_target_boxes
     here: box growth is a HIP kernel and this package has no CPU path; the GPU tests run it.)"""
-    flags = SMALL + ["--synthetic_images", "6", "--use_ensemble", "--blur_eval", "--cpu_blur", "--early_stop", "1",
+    flags = SMALL + ["--synthetic_images", "4", "--use_ensemble", "--blur_eval", "--cpu_blur", "--early_stop", "0",
                      "--tensorboard_path", str(tmp_path / "tb")]
     two, text = _launch(tmp_path, 2, "evaluate", flags, "sweep")
     cells = ["P%dE%d" % (p, e) for p in (1, 2, 3) for e in range(5)]
@@ -136,7 +136,7 @@ def test_evaluate_sweep_two_ranks_ensemble(tmp_path):
         assert sorted(r["result"]) == sorted(cells)
     for c in cells:
         a, b = two[0]["result"][c], two[1]["result"][c]
-        assert len(a["own_ids"]) == 2 and len(b["own_ids"]) == 2 and not set(a["own_ids"]) & set(b["own_ids"])
+        assert len(a["own_ids"]) == 1 and len(b["own_ids"]) == 1 and not set(a["own_ids"]) & set(b["own_ids"])
         assert a["merged_ids"] == b["merged_ids"] == sorted(a["own_ids"] + b["own_ids"])
         assert a["stats"] == b["stats"] and len(a["stats"]) == 12
         # oracle routing: blur type P -> net P for every exposure but the shortest of the sweep (1/25 bins to
