@@ -5,6 +5,8 @@
   * collate_fn, distributed helpers, meters      reference utils.py:474-785  (below)
 """
 import numpy as np
+import os
+
 import torch
 
 from . import blur_ops
@@ -157,6 +159,29 @@ def setup_for_distributed(is_master):
             builtin_print(*args, **kwargs)
 
     __builtin__.print = print
+
+
+_FORKSERVER = {"ctx": None}
+
+
+def loader_context():
+    """multiprocessing context for DataLoader workers: a fork SERVER started while this process has not touched the GPU yet,
+    None (= fork from this process) otherwise.  Why: forking a process that holds a GPU context write-protects its pinned
+    (GPU-registered) host memory for copy-on-write; every such fork makes the driver invalidate those mappings and park
+    the process's queues until they are restored -- measured as 20-45 s in which the GPU does nothing at the start of every
+    new loader (8 workers, `bench.py` sweep cells: 25 s per cell for 0.3 s of work).  Workers forked from a clean server
+    leave this process alone.  Must be called (first) BEFORE the first CUDA call: the server is started by fork + exec."""
+    if _FORKSERVER["ctx"] is None:
+        import multiprocessing as mp
+        if torch.cuda.is_initialized() or os.environ.get("DIB_LOADER_FORK"):
+            _FORKSERVER["ctx"] = False
+        else:
+            ctx = mp.get_context("forkserver")
+            ctx.set_forkserver_preload(["torch", "numpy", "detectinblur_amd.transforms", "detectinblur_amd.coco_utils", "detectinblur_amd.utils"])
+            from multiprocessing import forkserver
+            forkserver.ensure_running()
+            _FORKSERVER["ctx"] = ctx
+    return _FORKSERVER["ctx"] or None
 
 
 def init_distributed_mode(args):
