@@ -52,6 +52,7 @@ def _load(model, path):
 
 def main(args):
     reject_out_of_scope(args)
+    mp_ctx = utils.loader_context() if args.workers > 0 else None      # before anything touches the GPU (see utils.loader_context)
     utils.init_distributed_mode(args)
     print(args)
     seed_everything(args.distributed)
@@ -90,7 +91,7 @@ def main(args):
         ds, _ = get_coco(args.data_path, "val", tf, synthetic=synthetic)
         sampler = torch.utils.data.distributed.DistributedSampler(ds) if args.distributed else torch.utils.data.SequentialSampler(ds)
         return torch.utils.data.DataLoader(ds, batch_size=1, sampler=sampler, num_workers=args.workers, collate_fn=utils.collate_fn,
-                                           pin_memory=device.type == "cuda", worker_init_fn=_seed_worker)
+                                           pin_memory=device.type == "cuda", worker_init_fn=_seed_worker, multiprocessing_context=mp_ctx)
 
     ens_kw = dict(use_ensemble=args.use_ensemble, ensemble_models=ensemble, blur_estimator=estimator, LEHE=args.LEHE)
     results = {}

@@ -159,6 +159,7 @@ def log_coco_stats(writer, prefix, coco_evaluator, step):
 
 def main(args):
     reject_out_of_scope(args)
+    mp_ctx = utils.loader_context() if args.workers > 0 else None      # before anything touches the GPU (see utils.loader_context)
     utils.init_distributed_mode(args)
     print(args)
     seed_everything(args.distributed)
@@ -200,9 +201,10 @@ def main(args):
         batch_sampler = torch.utils.data.BatchSampler(train_sampler, args.batch_size, drop_last=True)
     pin = device.type == "cuda"
     data_loader = torch.utils.data.DataLoader(dataset, batch_sampler=batch_sampler, num_workers=args.workers, collate_fn=utils.collate_fn,
-                                              pin_memory=pin, worker_init_fn=_seed_worker)
+                                              pin_memory=pin, worker_init_fn=_seed_worker, multiprocessing_context=mp_ctx)
     mk_test = lambda ds, sm: torch.utils.data.DataLoader(ds, batch_size=1, sampler=sm, num_workers=args.workers,  # noqa: E731
-                                                         collate_fn=utils.collate_fn, pin_memory=pin, worker_init_fn=_seed_worker)
+                                                         collate_fn=utils.collate_fn, pin_memory=pin, worker_init_fn=_seed_worker,
+                                                         multiprocessing_context=mp_ctx)
     data_loader_test, data_loader_test_blur = mk_test(dataset_test, test_sampler), mk_test(dataset_test_blur, test_sampler_blur)
 
     print("Creating model")

@@ -66,6 +66,7 @@ def build_parser():
 
 
 def main(args):
+    mp_ctx = utils.loader_context() if args.workers > 0 else None      # before anything touches the GPU (see utils.loader_context)
     utils.init_distributed_mode(args)
     print(args)
     seed_everything(args.distributed)
@@ -90,10 +91,11 @@ def main(args):
         test_sampler = torch.utils.data.SequentialSampler(dataset_test)
     pin = device.type == "cuda"
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, sampler=train_sampler, num_workers=args.workers,
-                                         collate_fn=utils.collate_fn, drop_last=True, pin_memory=pin, worker_init_fn=_seed_worker)
+                                         collate_fn=utils.collate_fn, drop_last=True, pin_memory=pin, worker_init_fn=_seed_worker,
+                                         multiprocessing_context=mp_ctx)
     loader_test = torch.utils.data.DataLoader(dataset_test, batch_size=args.batch_size, sampler=test_sampler,
                                               num_workers=args.workers, collate_fn=utils.collate_fn, pin_memory=pin,
-                                              worker_init_fn=_seed_worker)
+                                              worker_init_fn=_seed_worker, multiprocessing_context=mp_ctx)
 
     print("Creating model")
     model = resnet18()

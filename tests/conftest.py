@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The DataLoader workers of the driver tests come from a fork server that must exist before this process touches the
+    # GPU (detectinblur_amd.utils.loader_context: a fork of a GPU process stalls the GPU for tens of seconds).
+    from detectinblur_amd import utils
+    utils.loader_context()
 
 
 def pytest_collection_modifyitems(config, items):
