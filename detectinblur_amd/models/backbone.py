@@ -1,6 +1,10 @@
 """ResNet-50 + FPN trunk of `fasterrcnn_resnet50_fpn` (reference models/faster_rcnn.py:367 builds it
-with torchvision's `resnet_fpn_backbone('resnet50', ...)`).  Stock PyTorch modules only: the
-convolutions run on MIOpen / hipBLASLt (MFMA); nothing here is hand-written.
+with torchvision's `resnet_fpn_backbone('resnet50', ...)`).  The convolutions and GEMMs are stock PyTorch-ROCm
+(MIOpen / hipBLASLt, MFMA); what this file adds around them, each switchable for A/B runs and each checked against the
+plain autograd graph (tests/test_detector_ops.py): the frozen batch-norm folded into the weights with a fused
+bias + residual + ReLU epilogue, the ReLU backward from a sign mask, conv1 + skip (or + downsample) of a bottleneck as one
+autograd node, and three shape-based detours where MIOpen's channels-last kernel is not the fast one (small-M 1x1 as
+GEMM, layer4's 3x3 through the planar kernels, wide-output 1x1 data gradients as GEMM).
 
 Layout matches torchvision's so that published checkpoints load unchanged:
 `body.conv1 / body.bn1 / body.layer{1..4}.{i}.{conv,bn}{1,2,3} / downsample.{0,1}` and
