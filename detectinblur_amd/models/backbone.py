@@ -139,7 +139,10 @@ def _as_gemm(x, conv, forward_only=False):
     M = x.shape[0] * x.shape[2] * x.shape[3]
     if M <= 16384 and conv.in_channels * conv.out_channels >= 512 * 1024:
         return True
-    return forward_only and conv.in_channels >= 1024 and M <= 65536
+    # forward alone (the entry nodes' forward pass; inference): the GEMM also wins at M <= 67,200 unless both channel
+    # counts are small -- 1024 -> 256 at M = 33,600: 0.193 -> 0.145 ms (b = 8); at b = 1 every 1x1 of the trunk but
+    # 64 -> 64: 2.28 -> 1.60 ms per image (scratch/t_b1_shapes.py)
+    return (forward_only or not torch.is_grad_enabled()) and M <= 67200 and max(conv.in_channels, conv.out_channels) >= 128
 
 
 # MIOpen's channels-last fp32 kernels are the fast ones for the large activations of this network; for the small-M, wide 3x3
@@ -149,12 +152,16 @@ NCHW_SMALL_3X3 = True
 
 
 def _as_planar(x, conv):
-    if not (NCHW_SMALL_3X3 and conv.kernel_size == (3, 3) and conv.groups == 1 and conv.in_channels >= 512 and x.is_cuda and x.dim() == 4
+    if not (NCHW_SMALL_3X3 and conv.kernel_size == (3, 3) and conv.groups == 1 and x.is_cuda and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)):
         return False
     ho = (x.shape[2] + 2 * conv.padding[0] - 3) // conv.stride[0] + 1
     wo = (x.shape[3] + 2 * conv.padding[1] - 3) // conv.stride[1] + 1
-    return x.shape[0] * ho * wo <= 16384
+    if conv.in_channels >= 512 and x.shape[0] * ho * wo <= 16384:
+        return True
+    # inference: at batch 1 the planar kernels win from 128 channels on wherever M <= 16,800 (256 -> 256 at 50 x 84:
+    # 147 -> 88 us; 4.28 -> 3.33 ms per image over the trunk's 3x3 convolutions, scratch/t_b1_shapes.py)
+    return not torch.is_grad_enabled() and conv.in_channels >= 128 and x.shape[0] * ho * wo <= 16800
 
 
 def conv1x1(x, weight, bias, conv):
@@ -425,11 +432,12 @@ class FeaturePyramidNetwork(nn.Module):
     def forward(self, feats):
         lat = lambda i: conv1x1(feats[i], self.inner_blocks[i].weight, self.inner_blocks[i].bias, self.inner_blocks[i])  # noqa: E731
         last = lat(-1)
-        outs = [self.layer_blocks[-1](last)]
+        out = lambda i, t: conv1x1(t, self.layer_blocks[i].weight, self.layer_blocks[i].bias, self.layer_blocks[i])  # noqa: E731
+        outs = [out(-1, last)]
         for i in range(len(feats) - 2, -1, -1):
             lateral = lat(i)
             last = lateral + F.interpolate(last, size=lateral.shape[-2:], mode="nearest")
-            outs.insert(0, self.layer_blocks[i](last))
+            outs.insert(0, out(i, last))
         outs.append(F.max_pool2d(outs[-1], 1, 2, 0))
         return OrderedDict(zip(["0", "1", "2", "3", "pool"], outs))
 

@@ -6,6 +6,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import detector_ops as ops
+from .backbone import conv1x1
 
 
 class AnchorGenerator(nn.Module):
@@ -63,7 +64,7 @@ class RPNHead(nn.Module):
     def forward(self, feats):
         logits, deltas = [], []
         for f in feats:
-            t = F.relu(self.conv(f))
+            t = F.relu(conv1x1(f, self.conv.weight, self.conv.bias, self.conv))      # shape-based kernel choice (backbone.conv1x1)
             logits.append(self.cls_logits(t))
             deltas.append(self.bbox_pred(t))
         return logits, deltas
