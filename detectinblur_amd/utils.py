@@ -176,11 +176,15 @@ def loader_context():
         if torch.cuda.is_initialized() or os.environ.get("DIB_LOADER_FORK"):
             _FORKSERVER["ctx"] = False
         else:
-            ctx = mp.get_context("forkserver")
-            ctx.set_forkserver_preload(["torch", "numpy", "detectinblur_amd.transforms", "detectinblur_amd.coco_utils", "detectinblur_amd.utils"])
-            from multiprocessing import forkserver
-            forkserver.ensure_running()
-            _FORKSERVER["ctx"] = ctx
+            try:
+                ctx = mp.get_context("forkserver")
+                ctx.set_forkserver_preload(["torch", "numpy", "detectinblur_amd.transforms", "detectinblur_amd.coco_utils", "detectinblur_amd.utils"])
+                from multiprocessing import forkserver
+                forkserver.ensure_running()
+                _FORKSERVER["ctx"] = ctx
+            except Exception as e:      # noqa: BLE001 -- no fork server on this platform: plain fork, with its stall
+                print("detectinblur_amd: no fork server for the DataLoader workers (%s: %s); forking from this process" % (type(e).__name__, e))
+                _FORKSERVER["ctx"] = False
     return _FORKSERVER["ctx"] or None
 
 
