@@ -26,17 +26,22 @@ VALU_KERNEL(k_add_u32, "v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 
 int main() {
   unsigned long long *out; CHECK(hipMalloc(&out, 256 * 8 * 4 * 4 * 8));
   const int iters = 4000;
+  hipEvent_t ev0, ev1; CHECK(hipEventCreate(&ev0)); CHECK(hipEventCreate(&ev1));
   std::vector<unsigned long long> h(256 * 8 * 4 * 4);
   // warm the clocks
   for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_pk_mul_f16, dim3(2048), dim3(256), 0, 0, out, iters, 1u);
   CHECK(hipDeviceSynchronize());
 #define RUN(K, WPS) { const int blocks = 256 * (WPS); \
+    hipLaunchKernelGGL(K, dim3(blocks), dim3(256), 0, 0, out, iters, 1u); \
+    CHECK(hipEventRecord(ev0, 0)); \
     for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(K, dim3(blocks), dim3(256), 0, 0, out, iters, 1u); \
-    CHECK(hipDeviceSynchronize()); CHECK(hipMemcpy(h.data(), out, blocks * 4 * 4 * 8, hipMemcpyDeviceToHost)); \
+    CHECK(hipEventRecord(ev1, 0)); \
+    CHECK(hipDeviceSynchronize()); float ms = 0; CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ms /= 3; CHECK(hipMemcpy(h.data(), out, blocks * 4 * 4 * 8, hipMemcpyDeviceToHost)); \
     std::vector<double> cyc, clk; for (int w = 0; w < blocks * 4; ++w) { cyc.push_back((double)h[w * 4]); clk.push_back((double)h[w * 4] / (double)h[w * 4 + 1] * 0.1); } \
     std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end()); \
     const double n = (double)iters * 64; \
-    printf("%-14s %d waves/SIMD: %.2f cycles per wave-instr per wave  -> %.2f cycles per wave-instr per SIMD; clock %.2f GHz\n", #K, WPS, cyc[cyc.size() / 2] / n, cyc[cyc.size() / 2] / n / (WPS), clk[clk.size() / 2]); }
+    const double wall_cyc = ms * 1e-3 * clk[clk.size() / 2] * 1e9; \
+    printf("%-14s %d waves/SIMD: %.2f cycles per wave-instr per wave  -> %.2f per SIMD if co-resident; clock %.2f GHz; launch %.3f ms = %.2f cycles per wave-instr per SIMD by wall time (wave life / launch = %.2f)\n", #K, WPS, cyc[cyc.size() / 2] / n, cyc[cyc.size() / 2] / n / (WPS), clk[clk.size() / 2], ms, wall_cyc / (n * (WPS)), cyc[cyc.size() / 2] / wall_cyc); }
   RUN(k_pk_mul_f16, 1) RUN(k_pk_mul_f16, 2) RUN(k_pk_mul_f16, 3) RUN(k_pk_mul_f16, 4) RUN(k_pk_mul_f16, 8)
   RUN(k_pk_fma_f16, 1) RUN(k_pk_fma_f16, 2) RUN(k_pk_fma_f16, 4) RUN(k_pk_fma_f16, 8)
   RUN(k_mul_f16, 1) RUN(k_mul_f16, 2) RUN(k_mul_f16, 4) RUN(k_mul_f16, 8)
