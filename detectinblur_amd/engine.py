@@ -335,77 +335,79 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
         def score(res):           # the box-IoU kernel of the matching on its own stream: never queued behind the detector
             with torch.cuda.stream(score_stream):
                 coco_evaluator.update(res)
-    for images_CPU, targets_CPU, blur_dicts in metric_logger.log_every(data_loader, 100, "Test:"):
-        if device.type == "cuda":
-            torch.cuda.synchronize()
-        model_time = time.time()
-        images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables = _to_device(
-            images_CPU, targets_CPU, blur_dicts, device, blurring_images, want_tables=gpu_blur or expand_target_boxes)
-        if gpu_blur and blurring_images:
-            blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU=psfs_GPU, add_noise=add_noise, noise_level=noise_level,
-                                           add_block=add_block, add_jpeg_artifact=add_jpeg_artifact,
-                                           jpeg_compressor=jpeg_compressor, tables=tables)
-        if expand_target_boxes and blurring_images:
-            targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU, tables=_tables_128(tables))
-            # the expanded boxes replace the ground truth's, annotation k <- target box k (reference :325-342,
-            # index-wise: where the target dropped a crowd / degenerate annotation the tail keeps its box)
-            for target in targets_GPU:
-                boxes = utils.convert_to_xywh(target["boxes"]).cpu().numpy().tolist()
-                anns = coco_evaluator.coco_gt.imgToAnns[int(target["image_id"].item())]
-                for k, ann in enumerate(anns):
-                    total_boxes += 1
-                    if k < len(boxes):
-                        ann["bbox"] = boxes[k]
-                    elif k + 1 == len(anns):             # counted once per image, at its last annotation (reference :336-341)
-                        faulty_boxes += 1
-                    else:
-                        print("Faulty " + str(len(anns) - k) + " times over.")
-        images_GPU = _to_float(images_GPU, ensemble_models[0] if use_ensemble else model, device)
-        norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
+    try:
+        for images_CPU, targets_CPU, blur_dicts in metric_logger.log_every(data_loader, 100, "Test:"):
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            model_time = time.time()
+            images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables = _to_device(
+                images_CPU, targets_CPU, blur_dicts, device, blurring_images, want_tables=gpu_blur or expand_target_boxes)
+            if gpu_blur and blurring_images:
+                blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU=psfs_GPU, add_noise=add_noise, noise_level=noise_level,
+                                               add_block=add_block, add_jpeg_artifact=add_jpeg_artifact,
+                                               jpeg_compressor=jpeg_compressor, tables=tables)
+            if expand_target_boxes and blurring_images:
+                targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU, tables=_tables_128(tables))
+                # the expanded boxes replace the ground truth's, annotation k <- target box k (reference :325-342,
+                # index-wise: where the target dropped a crowd / degenerate annotation the tail keeps its box)
+                for target in targets_GPU:
+                    boxes = utils.convert_to_xywh(target["boxes"]).cpu().numpy().tolist()
+                    anns = coco_evaluator.coco_gt.imgToAnns[int(target["image_id"].item())]
+                    for k, ann in enumerate(anns):
+                        total_boxes += 1
+                        if k < len(boxes):
+                            ann["bbox"] = boxes[k]
+                        elif k + 1 == len(anns):             # counted once per image, at its last annotation (reference :336-341)
+                            faulty_boxes += 1
+                        else:
+                            print("Faulty " + str(len(anns) - k) + " times over.")
+            images_GPU = _to_float(images_GPU, ensemble_models[0] if use_ensemble else model, device)
+            norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 
-        if use_ensemble:                                                 # reference :354-366
-            idx = list(range(len(ensemble_models)))
-            if blur_estimator is None:
-                k = get_network_index_to_use_oracle(blur_dicts, idx)
+            if use_ensemble:                                                 # reference :354-366
+                idx = list(range(len(ensemble_models)))
+                if blur_estimator is None:
+                    k = get_network_index_to_use_oracle(blur_dicts, idx)
+                else:
+                    batched, _ = batcher(images_GPU, None)
+                    est = _estimate(blur_estimator, batched.tensors, graphed)
+                    k = (get_network_index_to_use_blur_estimator_LEHE if LEHE else get_network_index_to_use_blur_estimator)(est, idx)
+                model = ensemble_models[k]
+                routes.append(k)
+            if blurring_images:
+                outputs = model(images_GPU, thetas=thetas, lambda1s=l1, lambda2s=l2, newMeans=norm_means, newSTDs=norm_stds)
             else:
-                batched, _ = batcher(images_GPU, None)
-                est = _estimate(blur_estimator, batched.tensors, graphed)
-                k = (get_network_index_to_use_blur_estimator_LEHE if LEHE else get_network_index_to_use_blur_estimator)(est, idx)
-            model = ensemble_models[k]
-            routes.append(k)
-        if blurring_images:
-            outputs = model(images_GPU, thetas=thetas, lambda1s=l1, lambda2s=l2, newMeans=norm_means, newSTDs=norm_stds)
-        else:
-            outputs = model(images_GPU, killWarp=True, newMeans=norm_means, newSTDs=norm_stds)
-        outputs = [{k: v.to("cpu") for k, v in t.items()} for t in outputs]
-        model_time = time.time() - model_time
-        res = {}
-        for t, o in zip(targets_GPU, outputs):
-            image_id = int(t["image_id"]) if "image_id" in t else count
-            res[image_id] = o
-            detections[image_id] = o
-            gt_boxes[image_id] = utils.convert_to_xywh(t["boxes"]).cpu()
-        evaluator_time = time.time()
-        if scorer is None:
-            coco_evaluator.update(res)                                   # reference :388-392
-        else:
-            pending.append(scorer.submit(score, res))                    # scored while the GPU runs the next image
-        evaluator_time = time.time() - evaluator_time
-        metric_logger.update(model_time=model_time, evaluator_time=evaluator_time)
-        count += 1
-        if early_stop is not None and count > early_stop:
-            break
-    if scorer is not None:
-        for f in pending:
-            f.result()                                                   # re-raises anything the scoring thread hit
-        scorer.shutdown()
+                outputs = model(images_GPU, killWarp=True, newMeans=norm_means, newSTDs=norm_stds)
+            outputs = [{k: v.to("cpu") for k, v in t.items()} for t in outputs]
+            model_time = time.time() - model_time
+            res = {}
+            for t, o in zip(targets_GPU, outputs):
+                image_id = int(t["image_id"]) if "image_id" in t else count
+                res[image_id] = o
+                detections[image_id] = o
+                gt_boxes[image_id] = utils.convert_to_xywh(t["boxes"]).cpu()
+            evaluator_time = time.time()
+            if scorer is None:
+                coco_evaluator.update(res)                                   # reference :388-392
+            else:
+                pending.append(scorer.submit(score, res))                    # scored while the GPU runs the next image
+            evaluator_time = time.time() - evaluator_time
+            metric_logger.update(model_time=model_time, evaluator_time=evaluator_time)
+            count += 1
+            if early_stop is not None and count > early_stop:
+                break
+    finally:                                                             # also on an error in the loop: no stray thread, thread count restored
+        if scorer is not None:
+            scorer.shutdown(wait=True)
+        torch.set_num_threads(n_threads)
+    for f in pending:
+        f.result()                                                       # re-raises anything the scoring thread hit
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     print("Number of Faulty boxes: " + str(faulty_boxes) + " Total number of boxes: " + str(total_boxes))
     coco_evaluator.synchronize_between_processes()                       # a collective on every rank, shards empty or not
     coco_evaluator.accumulate()
     stats = coco_evaluator.summarize() if utils.is_main_process() else coco_evaluator.coco_eval["bbox"].summarize()
-    torch.set_num_threads(n_threads)
     has_gt = len(coco_evaluator.coco_gt.dataset.get("annotations", [])) > 0
     return EvaluationResult(coco_evaluator, detections=detections, targets=gt_boxes, routes=routes, meters=metric_logger,
                             coco_stats=stats if has_gt else None)
