@@ -22,6 +22,11 @@ VALU_KERNEL(k_pk_fma_f16, "v_pk_fma_f16 %0, %0, %8, %0\n v_pk_fma_f16 %1, %1, %8
 VALU_KERNEL(k_mul_f16, "v_mul_f16 %0, %0, %8\n v_mul_f16 %1, %1, %8\n v_mul_f16 %2, %2, %8\n v_mul_f16 %3, %3, %8\n v_mul_f16 %4, %4, %8\n v_mul_f16 %5, %5, %8\n v_mul_f16 %6, %6, %8\n v_mul_f16 %7, %7, %8")
 VALU_KERNEL(k_fma_f32, "v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %1, %1, %8, %1\n v_fma_f32 %2, %2, %8, %2\n v_fma_f32 %3, %3, %8, %3\n v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %5, %5, %8, %5\n v_fma_f32 %6, %6, %8, %6\n v_fma_f32 %7, %7, %8, %7")
 VALU_KERNEL(k_add_u32, "v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8")
+VALU_KERNEL(k_pk_add_f16, "v_pk_add_f16 %0, %0, %8\n v_pk_add_f16 %1, %1, %8\n v_pk_add_f16 %2, %2, %8\n v_pk_add_f16 %3, %3, %8\n v_pk_add_f16 %4, %4, %8\n v_pk_add_f16 %5, %5, %8\n v_pk_add_f16 %6, %6, %8\n v_pk_add_f16 %7, %7, %8")
+VALU_KERNEL(k_pk_mul_add, "v_pk_mul_f16 %0, %1, %8\n v_pk_add_f16 %2, %2, %0\n v_pk_mul_f16 %3, %4, %8\n v_pk_add_f16 %5, %5, %3\n v_pk_mul_f16 %0, %6, %8\n v_pk_add_f16 %7, %7, %0\n v_pk_mul_f16 %3, %1, %8\n v_pk_add_f16 %2, %2, %3")
+VALU_KERNEL(k_pk_plus_plain, "v_pk_mul_f16 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_pk_mul_f16 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_pk_mul_f16 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_pk_mul_f16 %6, %6, %8\n v_add_u32 %7, %7, %8")
+VALU_KERNEL(k_add_f16, "v_add_f16 %0, %0, %8\n v_add_f16 %1, %1, %8\n v_add_f16 %2, %2, %8\n v_add_f16 %3, %3, %8\n v_add_f16 %4, %4, %8\n v_add_f16 %5, %5, %8\n v_add_f16 %6, %6, %8\n v_add_f16 %7, %7, %8")
+VALU_KERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_add_u16 %3, %3, %8\n v_pk_add_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n v_pk_add_u16 %6, %6, %8\n v_pk_add_u16 %7, %7, %8")
 
 int main() {
   unsigned long long *out; CHECK(hipMalloc(&out, 256 * 8 * 4 * 4 * 8));
@@ -47,5 +52,7 @@ int main() {
   RUN(k_mul_f16, 1) RUN(k_mul_f16, 2) RUN(k_mul_f16, 4) RUN(k_mul_f16, 8)
   RUN(k_fma_f32, 1) RUN(k_fma_f32, 2) RUN(k_fma_f32, 4) RUN(k_fma_f32, 8)
   RUN(k_add_u32, 1) RUN(k_add_u32, 2) RUN(k_add_u32, 4) RUN(k_add_u32, 8)
+  RUN(k_pk_add_f16, 2) RUN(k_pk_add_f16, 8) RUN(k_pk_mul_add, 2) RUN(k_pk_mul_add, 8) RUN(k_pk_plus_plain, 2) RUN(k_pk_plus_plain, 8)
+  RUN(k_add_f16, 2) RUN(k_add_f16, 8) RUN(k_pk_add_u16, 2) RUN(k_pk_add_u16, 8)
   return 0;
 }
