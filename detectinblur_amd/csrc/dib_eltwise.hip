@@ -72,6 +72,30 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(float4 *__restrict__ a
   }
 }
 
+// FPN top-down merge in one pass, in place on the lateral convolution's output:
+//   x[n, h, w, :] += bias[:] + top[n, sh(h), sw(w), :]      (lateral + bias + interpolate(top, size=(H, W), mode="nearest"))
+// with ATen's nearest source index, src = min(int(floorf(dst * float(in) / out)), in - 1).  Stock PyTorch runs it as a bias add,
+// an upsample that writes a full-size tensor and an add that reads it back (7 tensor passes); this is 2.25.
+__global__ __launch_bounds__(256) void topdown_merge_kernel(float4 *__restrict__ x, const float4 *__restrict__ bias,
+                                                           const float4 *__restrict__ top, int H, int W, int Ht, int Wt, int C4,
+                                                           float scale_h, float scale_w, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long p = i / C4;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const long long n = p / H;
+    const int sh = min((int)floorf((float)h * scale_h), Ht - 1), sw = min((int)floorf((float)w * scale_w), Wt - 1);
+    float4 v = x[i];
+    const float4 b = bias[c];
+    const float4 t = top[((n * Ht + sh) * Wt + sw) * C4 + c];
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    x[i] = v;
+  }
+}
+
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bias_act_scalar_kernel(float *__restrict__ x, const float *__restrict__ bias,
                                                              const float *__restrict__ res, long long n, int C) {
@@ -152,6 +176,23 @@ extern "C" int dib_scatter_add_nhwc(float *a_dev, const float *b_dev, int N, int
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)a_dev, (const float4 *)b_dev, Hs, Ws,
                      C / 4, H, W, stride, n4);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
+
+// x[N, H, W, C] (channels-last fp32, in place) += bias[C] + top[N, Ht, Wt, C] at the nearest-neighbour source pixel;
+// C % 4 == 0, 16-byte aligned.
+extern "C" int dib_fpn_topdown_merge_nhwc(float *x_dev, const float *bias_dev, const float *top_dev, int N, int H, int W, int Ht, int Wt,
+                                          int C, void *stream) {
+  if (N < 0 || H <= 0 || W <= 0 || Ht <= 0 || Wt <= 0 || C <= 0 || (C % 4) != 0) { set_error("dib_fpn_topdown_merge_nhwc: bad shape (C %% 4 == 0)"); return DIB_EINVAL; }
+  if (N == 0) return DIB_OK;
+  if (!x_dev || !bias_dev || !top_dev) { set_error("dib_fpn_topdown_merge_nhwc: null pointer"); return DIB_EINVAL; }
+  if ((((uintptr_t)x_dev | (uintptr_t)bias_dev | (uintptr_t)top_dev) & 15) != 0) { set_error("dib_fpn_topdown_merge_nhwc: tensors must be 16-byte aligned"); return DIB_EINVAL; }
+  const long long n4 = (long long)N * H * W * (C / 4);
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(topdown_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)x_dev, (const float4 *)bias_dev,
+                     (const float4 *)top_dev, H, W, Ht, Wt, C / 4, (float)Ht / (float)H, (float)Wt / (float)W, n4);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }

@@ -417,6 +417,45 @@ class ResNet50Body(nn.Module):
         return [c2, c3, c4, c5]
 
 
+FUSE_TOPDOWN = True       # FPN: lateral bias + nearest upsample of the level above + add as one in-place pass
+
+
+class _TopDownMerge(torch.autograd.Function):
+    """inner = (lateral conv output + bias) + F.interpolate(top, size=lateral.shape[-2:], mode="nearest"), in place on the
+    convolution's output (dib_fpn_topdown_merge_nhwc).  Backward: the lateral's gradient IS the incoming one, the bias
+    gradient its sum over pixels, the upper level's ATen's own nearest-upsample backward -- what autograd computes for the
+    unfused graph."""
+
+    @staticmethod
+    def forward(ctx, x, bias, top):
+        from .. import _lib
+        N, C, H, W = x.shape
+        ctx.top_shape = tuple(top.shape)
+        ctx.mark_dirty(x)
+        _lib.check(_lib.lib().dib_fpn_topdown_merge_nhwc(x.data_ptr(), bias.data_ptr(), top.data_ptr(), N, H, W, top.shape[2], top.shape[3], C,
+                                                         torch.cuda.current_stream().cuda_stream))
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        need_x, need_b, need_t = ctx.needs_input_grad
+        g_b = g.sum((0, 2, 3)) if need_b else None
+        g_t = None
+        if need_t:
+            g_t = torch.ops.aten.upsample_nearest2d_backward(g, list(g.shape[-2:]), list(ctx.top_shape), None, None)
+        return (g if need_x else None), g_b, g_t
+
+
+def topdown_merge(lateral, bias, top):
+    """lateral (a convolution output WITHOUT its bias) + bias + nearest-upsampled `top`."""
+    cl = lambda t: t.is_contiguous(memory_format=torch.channels_last) and not (t.data_ptr() & 15)   # noqa: E731
+    if (FUSE_TOPDOWN and FUSE_EPILOGUE and lateral.is_cuda and lateral.dtype == torch.float32 and top.dtype == torch.float32
+            and lateral.dim() == 4 and lateral.shape[1] % 4 == 0 and lateral.shape[:2] == top.shape[:2] and cl(lateral) and cl(top)
+            and bias.dtype == torch.float32):
+        return _TopDownMerge.apply(lateral, bias.contiguous(), top)
+    return lateral + bias.reshape(1, -1, 1, 1) + F.interpolate(top, size=lateral.shape[-2:], mode="nearest")
+
+
 class FeaturePyramidNetwork(nn.Module):
     """Top-down pathway with lateral 1x1 and output 3x3 convolutions, plus a stride-2 max-pool level."""
 
@@ -435,8 +474,8 @@ class FeaturePyramidNetwork(nn.Module):
         out = lambda i, t: conv1x1(t, self.layer_blocks[i].weight, self.layer_blocks[i].bias, self.layer_blocks[i])  # noqa: E731
         outs = [out(-1, last)]
         for i in range(len(feats) - 2, -1, -1):
-            lateral = lat(i)
-            last = lateral + F.interpolate(last, size=lateral.shape[-2:], mode="nearest")
+            blk = self.inner_blocks[i]
+            last = topdown_merge(conv1x1(feats[i], blk.weight, None, blk), blk.bias, last)
             outs.insert(0, out(i, last))
         outs.append(F.max_pool2d(outs[-1], 1, 2, 0))
         return OrderedDict(zip(["0", "1", "2", "3", "pool"], outs))

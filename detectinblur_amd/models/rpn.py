@@ -6,7 +6,9 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import detector_ops as ops
-from .backbone import conv1x1
+from .backbone import bias_act, conv1x1
+
+FUSE_HEAD = True     # RPN head: fused bias + ReLU epilogue, one convolution for both predictors (False: the plain module graph)
 
 
 class AnchorGenerator(nn.Module):
@@ -62,11 +64,26 @@ class RPNHead(nn.Module):
             nn.init.constant_(l.bias, 0)
 
     def forward(self, feats):
+        """Same values as conv -> relu -> (cls_logits, bbox_pred) per level, in fewer passes over the 256-channel hidden
+        tensor (550 MB at the 200 x 336 level of a batch of 8): bias + ReLU as one in-place epilogue with the sign mask for
+        the backward pass, and the two 1 x 1 predictors as ONE convolution with A + 4A output channels -- the hidden tensor
+        is read once forward, and its gradient comes out of one data-gradient kernel instead of two plus autograd's add."""
         logits, deltas = [], []
+        A = self.cls_logits.out_channels
+        fused = FUSE_HEAD and feats and feats[0].is_cuda
+        if fused:
+            w = torch.cat([self.cls_logits.weight, self.bbox_pred.weight])
+            b = torch.cat([self.cls_logits.bias, self.bbox_pred.bias])
         for f in feats:
-            t = F.relu(conv1x1(f, self.conv.weight, self.conv.bias, self.conv))      # shape-based kernel choice (backbone.conv1x1)
-            logits.append(self.cls_logits(t))
-            deltas.append(self.bbox_pred(t))
+            if not fused:
+                t = F.relu(conv1x1(f, self.conv.weight, self.conv.bias, self.conv))
+                logits.append(self.cls_logits(t))
+                deltas.append(self.bbox_pred(t))
+                continue
+            t = bias_act(conv1x1(f, self.conv.weight, None, self.conv), self.conv.bias, relu=True)   # shape-based kernel choice
+            both = F.conv2d(t, w, b)
+            logits.append(both[:, :A])
+            deltas.append(both[:, A:])
         return logits, deltas
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -205,6 +205,12 @@ int dib_add_relu_mask(float *a_dev, const float *b_dev, const unsigned char *mas
  * a[n, ys * stride, xs * stride, :] += b[n, ys, xs, :] (channels-last fp32, C % 4 == 0) -- instead of a zero-filled
  * full-size gradient and a full-size add. */
 int dib_scatter_add_nhwc(float *a_dev, const float *b_dev, int N, int H, int W, int Hs, int Ws, int C, int stride, void *stream);
+/* FPN top-down merge (torchvision FeaturePyramidNetwork.forward: inner = lateral + interpolate(top, size, "nearest")) in one
+ * in-place pass on the lateral convolution's output: x[n, h, w, :] += bias[:] + top[n, sh, sw, :], sh = min(int(floorf(h *
+ * float(Ht) / H)), Ht - 1) (ATen's nearest index) -- instead of a bias add, an upsample that writes a full-size tensor and an
+ * add that reads it back. */
+int dib_fpn_topdown_merge_nhwc(float *x_dev, const float *bias_dev, const float *top_dev, int N, int H, int W, int Ht, int Wt, int C,
+                               void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Post-blur corruption chain of manual_blur (reference models/blur_functions.py:72-81) in one pass:
