@@ -134,41 +134,43 @@ class RegionProposalNetwork(nn.Module):
         return [boxes[i, :c] for i, c in enumerate(counts_host)], [scores[i, :c] for i, c in enumerate(counts_host)]
 
     def _filter(self, proposals, objectness, sizes, counts):
-        """Per-level top-k, clip, sort, NMS across levels, top post-NMS: fixed shapes, no host synchronisation (what a HIP
+        """Per-level top-k, clip, NMS per level, top post-NMS over the levels: fixed shapes, no host synchronisation (what a HIP
         graph can hold).  sizes: [N, 2] (w, h) on the proposals' device.  Returns boxes [N, post, 4], scores [N, post] and
-        the number of rows that are real, per image."""
-        N = proposals.shape[0]
+        the number of rows that are real, per image.
+
+        torchvision runs ONE batched NMS per image over all levels (boxes of different levels moved apart); boxes of different
+        levels never suppress each other, so the same survivors come out of one NMS set per (image, level) -- N x L independent
+        sets of <= pre-NMS-top-n boxes, already sorted by the per-level top-k, instead of N sets of their sum: the greedy pass,
+        sequential in blocks of 64 boxes, is 4 x shorter (32 instead of 138 block steps at the training sizes) and the
+        suppression mask has 4 x fewer words.  The survivors of all levels are then ranked by score (top-k), which is the
+        order batched_nms returns."""
+        N, L = proposals.shape[0], len(counts)
         objectness = objectness.detach().reshape(N, -1)
-        levels = torch.cat([torch.full((n,), i, dtype=torch.int64, device=proposals.device) for i, n in enumerate(counts)])
-        # top-k per level before NMS
-        idx, off = [], 0
-        for ob in objectness.split(counts, 1):
-            k = min(self._n(self._pre), ob.shape[1])
-            idx.append(ob.topk(k, dim=1)[1] + off)
-            off += ob.shape[1]
-        idx = torch.cat(idx, dim=1)
-        rows = torch.arange(N, device=proposals.device)[:, None]
-        objectness, levels, proposals = objectness[rows, idx], levels[None].expand(N, -1)[rows, idx], proposals[rows, idx]
-        # From here on every image goes through the same tensor ops at once, and nothing is compacted
-        # before the NMS: boxes that torchvision would drop as too small are flagged invalid instead
-        # (they are never kept and never suppress).  One host sync per batch (the kept counts) instead
-        # of two per image, ~15 launches instead of ~20 per image.
-        x = proposals[..., 0::2].clamp(min=0).minimum(sizes[:, None, 0:1])
-        y = proposals[..., 1::2].clamp(min=0).minimum(sizes[:, None, 1:2])
+        K = max(min(self._n(self._pre), n) for n in counts)
+        lv_scores = objectness.new_full((N, L, K), float("-inf"))
+        lv_boxes = proposals.new_zeros((N, L, K, 4))
+        off = 0
+        for l, n in enumerate(counts):                                       # top-k per level before NMS (sorted by score)
+            k = min(self._n(self._pre), n)
+            s, i = objectness[:, off:off + n].topk(k, dim=1)
+            lv_scores[:, l, :k] = s
+            lv_boxes[:, l, :k] = proposals[:, off:off + n].gather(1, i[..., None].expand(-1, -1, 4))
+            off += n
+        real = lv_scores > float("-inf")
+        # Every image and level goes through the same tensor ops at once, and nothing is compacted before the NMS: boxes
+        # that torchvision would drop as too small are flagged invalid instead (they are never kept and never suppress).
+        x = lv_boxes[..., 0::2].clamp(min=0).minimum(sizes[:, None, None, 0:1])
+        y = lv_boxes[..., 1::2].clamp(min=0).minimum(sizes[:, None, None, 1:2])
         boxes = torch.stack((x[..., 0], y[..., 0], x[..., 1], y[..., 1]), dim=-1)                        # clip_boxes_to_image
-        valid = ((boxes[..., 2] - boxes[..., 0]) >= self.min_size) & ((boxes[..., 3] - boxes[..., 1]) >= self.min_size)
-        scores, order = objectness.sort(dim=1, descending=True)
-        boxes = boxes.gather(1, order[..., None].expand(-1, -1, 4))
-        levels, valid = levels.gather(1, order), valid.gather(1, order)
-        # batched_nms: boxes of different levels are moved apart by (largest coordinate + 1) per level
-        top = torch.where(valid[..., None], boxes, boxes.new_zeros(())).amax(dim=(1, 2))
-        shifted = boxes + (levels.to(boxes) * (top[:, None] + 1))[..., None]
-        keep, count = ops.nms_sets_sorted(shifted, valid, self.nms_thresh)
-        post = self._n(self._post)
-        keep = keep[:, :post]
-        boxes = boxes.gather(1, keep[..., None].expand(-1, -1, 4))
-        scores = scores.gather(1, keep)
-        return boxes, scores, count.clamp(max=post)
+        valid = real & ((boxes[..., 2] - boxes[..., 0]) >= self.min_size) & ((boxes[..., 3] - boxes[..., 1]) >= self.min_size)
+        keep, count = ops.nms_sets_sorted(boxes.reshape(N * L, K, 4), valid.reshape(N * L, K), self.nms_thresh)
+        kept = torch.arange(K, device=keep.device)[None, :] < count[:, None]
+        scores = torch.where(kept, lv_scores.reshape(N * L, K).gather(1, keep), lv_scores.new_full((), float("-inf"))).reshape(N, L * K)
+        boxes = boxes.reshape(N * L, K, 4).gather(1, keep[..., None].expand(-1, -1, 4)).reshape(N, L * K, 4)
+        post = min(self._n(self._post), L * K)
+        scores, top = scores.topk(post, dim=1)                               # survivors of all levels in score order
+        boxes = boxes.gather(1, top[..., None].expand(-1, -1, 4))
+        return boxes, scores, count.reshape(N, L).sum(1).clamp(max=post)
 
     def propose_static(self, feats, anchors, sizes):
         """head + decoding + `_filter` on a list of feature maps: the sync-free part of `forward` in inference."""

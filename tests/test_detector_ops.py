@@ -400,11 +400,14 @@ def test_small_m_1x1_convolutions_through_the_gemm_path_equal_conv2d():
     finally:
         B.LINEAR_1X1 = True
     for a, b in zip(outs[True], outs[False]):
-        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))
-    # large-M shapes stay on MIOpen: identical object path, bit-identical output
+        assert float((a - b).norm()) <= 2e-4 * float(b.norm())
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-3 * float(b.abs().max()))
+    # large-M shapes stay on MIOpen: the same call (MIOpen may still switch kernels between two calls on a fresh box while
+    # its search results arrive, so the comparison allows summation-order noise)
     small = torch.nn.Conv2d(64, 256, 1, bias=False).cuda()
     xs = torch.randn(2, 64, 40, 40, device="cuda").contiguous(memory_format=torch.channels_last)
-    assert torch.equal(B.conv1x1(xs, small.weight, None, small), torch.nn.functional.conv2d(xs, small.weight))
+    assert not B._as_gemm(xs, small)
+    assert torch.allclose(B.conv1x1(xs, small.weight, None, small), torch.nn.functional.conv2d(xs, small.weight), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.gpu
@@ -520,3 +523,59 @@ def test_rpn_head_fused_predictors_equal_the_module_graph():
     for group in (1, 2):
         for a, b in zip(res[True][group], res[False][group]):
             assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-6          # a ReLU sign can flip on 1e-7 noise
+
+
+def _reference_filter(props, obj, counts, pre, post, size_wh, thresh, min_size):
+    """torchvision's RegionProposalNetwork.filter_proposals for ONE image, restated with plain torch ops: per-level top-k,
+    clip, drop small boxes, one batched NMS over all levels, top post-NMS."""
+    from detectinblur_amd.models import detector_ops as ops
+    idx, lv, off = [], [], 0
+    for l, n in enumerate(counts):
+        k = min(pre, n)
+        idx.append(obj[off:off + n].topk(k)[1] + off)
+        lv.append(torch.full((k,), l, dtype=torch.int64, device=obj.device))
+        off += n
+    idx, lv = torch.cat(idx), torch.cat(lv)
+    b, s = props[idx].clone(), obj[idx]
+    b[:, 0::2] = b[:, 0::2].clamp(min=0, max=size_wh[0])
+    b[:, 1::2] = b[:, 1::2].clamp(min=0, max=size_wh[1])
+    ok = ((b[:, 2] - b[:, 0]) >= min_size) & ((b[:, 3] - b[:, 1]) >= min_size)
+    b, s, lv = b[ok], s[ok], lv[ok]
+    keep = ops.batched_nms(b, s, lv, thresh)[:post]
+    return b[keep], s[keep]
+
+
+def _check_rpn_filter(device):
+    from detectinblur_amd.models import rpn as R
+    torch.manual_seed(31)
+    rpn = R.RegionProposalNetwork(None, None, 0.7, 0.3, 256, 0.5, dict(training=300, testing=150), dict(training=200, testing=100), 0.7)
+    counts = [1200, 300, 75, 27]
+    N, A = 3, sum(counts)
+    for training in (True, False):
+        rpn.train(training)
+        cxy = torch.rand(N, A, 2, device=device) * torch.tensor([220.0, 160.0], device=device) - 10
+        wh = torch.rand(N, A, 2, device=device) * 60
+        wh[:, ::17] = 0.0                                              # degenerate boxes: dropped by the size test
+        props = torch.cat([cxy - wh / 2, cxy + wh / 2], dim=-1)
+        obj = torch.randn(N * A, 1, device=device)
+        sizes = [(150, 200), (140, 190), (150, 180)]                   # (h, w)
+        boxes, scores = rpn.filter_proposals(props, obj, sizes, counts)
+        (pb, ok), _ = rpn.filter_proposals(props, obj, sizes, counts, padded=True)
+        pre, post = (300, 200) if training else (150, 100)
+        for i in range(N):
+            wb, ws = _reference_filter(props[i], obj.view(N, A)[i], counts, pre, post, (float(sizes[i][1]), float(sizes[i][0])), 0.7, rpn.min_size)
+            assert boxes[i].shape == wb.shape and 0 < wb.shape[0] <= post, (training, i, boxes[i].shape, wb.shape)
+            assert torch.equal(scores[i], ws) and torch.equal(boxes[i], wb)
+            assert int(ok[i].sum()) == wb.shape[0] and torch.equal(pb[i][ok[i]], wb)
+
+
+def test_rpn_filter_per_level_sets_equal_torchvisions_batched_nms_on_cpu():
+    """RegionProposalNetwork._filter (one NMS set per image and level, survivors ranked by a top-k) against the plain
+    restatement of torchvision's filter_proposals (one batched NMS per image over all levels): same boxes, same scores,
+    same order, in training and in inference mode, ragged levels, degenerate boxes, unpadded and padded forms."""
+    _check_rpn_filter(torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_rpn_filter_per_level_sets_equal_torchvisions_batched_nms_on_gpu():
+    _check_rpn_filter(torch.device("cuda"))
