@@ -4,6 +4,7 @@
 // activation (bias add, residual add, ReLU); here it is one pass, in place on the convolution output.
 // Pure streaming: 8 bytes per element without a residual, 12 with one -> HBM-bound.
 #include "dib_common.h"
+#include <stdlib.h>
 
 namespace dib {
 
@@ -111,6 +112,16 @@ __global__ __launch_bounds__(256) void bias_act_scalar_kernel(float *__restrict_
 
 using namespace dib;
 
+// Launch shape of the streaming kernels above: ONE float4 per thread (the grid-stride loops only matter past 2^30 workgroups).
+// Measured on the 550 MB tensors of the detector's first pyramid level (scratch/ubench/ub_stream.hip): 185 us (5.9 TB/s) against
+// 220 us (5.0 TB/s) with the grid capped at 32 workgroups per CU, 197 against 245 us with the sign mask.
+static long long max_blocks_from_env() {       // DIB_ELTWISE_MAX_BLOCKS: A/B knob for that measurement (8192 = the old cap)
+  const char *e = getenv("DIB_ELTWISE_MAX_BLOCKS");
+  const long long v = e ? atoll(e) : 0;
+  return v > 0 ? v : (1ll << 30);
+}
+static const long long MAX_BLOCKS = max_blocks_from_env();
+
 // x_dev: [n_elems] fp32 viewed as [..., C] with the channel fastest (NHWC storage), updated in place:
 //   x = act(x + bias[c] (+ residual)),  act = ReLU when relu != 0.
 static int bias_act_impl(float *x_dev, const float *bias_dev, const float *residual_dev, long long n_elems, int C, int relu,
@@ -142,7 +153,7 @@ extern "C" int dib_relu_mask_backward(const float *grad_in_dev, const unsigned c
   if ((((uintptr_t)grad_in_dev | (uintptr_t)grad_out_dev) & 15) != 0) { set_error("dib_relu_mask_backward: tensors must be 16-byte aligned"); return DIB_EINVAL; }
   const long long n4 = n_elems / 4;
   long long blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)grad_in_dev, mask_dev,
                      (float4 *)grad_out_dev, n4);
   DIB_HIP_CHECK(hipGetLastError());
@@ -157,7 +168,7 @@ extern "C" int dib_add_relu_mask(float *a_dev, const float *b_dev, const unsigne
   if ((((uintptr_t)a_dev | (uintptr_t)b_dev) & 15) != 0) { set_error("dib_add_relu_mask: tensors must be 16-byte aligned"); return DIB_EINVAL; }
   const long long n4 = n_elems / 4;
   long long blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (mask_dev) hipLaunchKernelGGL(add_mask_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)a_dev, (const float4 *)b_dev, mask_dev, n4);
   else hipLaunchKernelGGL(add_mask_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)a_dev, (const float4 *)b_dev, (const unsigned char *)nullptr, n4);
   DIB_HIP_CHECK(hipGetLastError());
@@ -173,7 +184,7 @@ extern "C" int dib_scatter_add_nhwc(float *a_dev, const float *b_dev, int N, int
   if ((((uintptr_t)a_dev | (uintptr_t)b_dev) & 15) != 0) { set_error("dib_scatter_add_nhwc: tensors must be 16-byte aligned"); return DIB_EINVAL; }
   const long long n4 = (long long)N * Hs * Ws * (C / 4);
   long long blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)a_dev, (const float4 *)b_dev, Hs, Ws,
                      C / 4, H, W, stride, n4);
   DIB_HIP_CHECK(hipGetLastError());
@@ -190,7 +201,7 @@ extern "C" int dib_fpn_topdown_merge_nhwc(float *x_dev, const float *bias_dev, c
   if ((((uintptr_t)x_dev | (uintptr_t)bias_dev | (uintptr_t)top_dev) & 15) != 0) { set_error("dib_fpn_topdown_merge_nhwc: tensors must be 16-byte aligned"); return DIB_EINVAL; }
   const long long n4 = (long long)N * H * W * (C / 4);
   long long blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   hipLaunchKernelGGL(topdown_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)x_dev, (const float4 *)bias_dev,
                      (const float4 *)top_dev, H, W, Ht, Wt, C / 4, (float)Ht / (float)H, (float)Wt / (float)W, n4);
   DIB_HIP_CHECK(hipGetLastError());
@@ -206,7 +217,7 @@ static int bias_act_impl(float *x_dev, const float *bias_dev, const float *resid
   const bool vec = (C % 4 == 0) && (((uintptr_t)x_dev | (uintptr_t)bias_dev | (uintptr_t)residual_dev) & 15) == 0;
   const long long n = vec ? n_elems / 4 : n_elems;
   long long blocks = (n + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride: 32 workgroups per CU
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
 #define DIB_LAUNCH(RES, RELU)                                                                                         \
   do {                                                                                                                \
     if (vec && mask_dev) hipLaunchKernelGGL((bias_act_vec4_kernel<RES, true, true>), dim3((unsigned)blocks), dim3(256), 0, s,        \
