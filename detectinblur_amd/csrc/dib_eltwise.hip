@@ -97,6 +97,84 @@ __global__ __launch_bounds__(256) void topdown_merge_kernel(float4 *__restrict__
   }
 }
 
+// ResNet stem: bias + ReLU + 3x3 / stride 2 / padding 1 max-pool of the first convolution's output in ONE pass.
+// relu and max commute, so pooled = relu(max over the window of (x + bias)); the backward pass needs, per pooled element, only
+// WHICH window position won (4 bits; 15 = the maximum was not positive, no gradient): the 550 MB activation is neither written
+// back nor re-read, and ATen's int64 index tensor (2 x the pooled output) disappears.  Window scan order and the strict `>`
+// are ATen's (max_pool2d: first maximum in row-major window order).
+__global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ bias,
+                                                           float4 *__restrict__ out, unsigned short *__restrict__ arg, int H, int W,
+                                                           int Ho, int Wo, int C4, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long p = i / C4;
+    const int ow = (int)(p % Wo);
+    p /= Wo;
+    const int oh = (int)(p % Ho);
+    const long long n = p / Ho;
+    const float4 b = bias[c];
+    const float ninf = -__builtin_inff();
+    float4 m = make_float4(ninf, ninf, ninf, ninf);
+    unsigned ax = 15, ay = 15, az = 15, aw = 15;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = oh * 2 - 1 + dh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = ow * 2 - 1 + dw;
+        if (w < 0 || w >= W) continue;
+        float4 v = x[((n * H + h) * W + w) * C4 + c];
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        const unsigned k = dh * 3 + dw;
+        if (v.x > m.x) { m.x = v.x; ax = k; }
+        if (v.y > m.y) { m.y = v.y; ay = k; }
+        if (v.z > m.z) { m.z = v.z; az = k; }
+        if (v.w > m.w) { m.w = v.w; aw = k; }
+      }
+    }
+    if (!(m.x > 0.f)) { m.x = 0.f; ax = 15; }
+    if (!(m.y > 0.f)) { m.y = 0.f; ay = 15; }
+    if (!(m.z > 0.f)) { m.z = 0.f; az = 15; }
+    if (!(m.w > 0.f)) { m.w = 0.f; aw = 15; }
+    out[i] = m;
+    arg[i] = (unsigned short)(ax | (ay << 4) | (az << 8) | (aw << 12));
+  }
+}
+
+// Its backward: the gradient of the convolution output, dense (every input pixel belongs to at most 2 x 2 windows; it takes the
+// pooled gradient of those whose recorded winner it is).  One pass: pooled gradient + 2 bytes per 4 pooled elements in,
+// full-size gradient out -- instead of ATen's max-pool backward plus the ReLU mask pass.
+__global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const float4 *__restrict__ g_out, const unsigned short *__restrict__ arg,
+                                                           float4 *__restrict__ g_in, int H, int W, int Ho, int Wo, int C4, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long p = i / C4;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const long long n = p / H;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int oh0 = h >> 1, oh1 = (h + 1) >> 1, ow0 = w >> 1, ow1 = (w + 1) >> 1;     // windows oh with 2 oh - 1 <= h <= 2 oh + 1
+    for (int oh = oh0; oh <= oh1; ++oh) {
+      if (oh >= Ho) continue;
+      const unsigned dh = (unsigned)(h - (oh * 2 - 1));
+      for (int ow = ow0; ow <= ow1; ++ow) {
+        if (ow >= Wo) continue;
+        const unsigned k = dh * 3 + (unsigned)(w - (ow * 2 - 1));
+        const long long j = ((n * Ho + oh) * Wo + ow) * C4 + c;
+        const unsigned a = arg[j];
+        const float4 go = g_out[j];
+        if ((a & 15u) == k) g.x += go.x;
+        if (((a >> 4) & 15u) == k) g.y += go.y;
+        if (((a >> 8) & 15u) == k) g.z += go.z;
+        if ((a >> 12) == k) g.w += go.w;
+      }
+    }
+    g_in[i] = g;
+  }
+}
+
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bias_act_scalar_kernel(float *__restrict__ x, const float *__restrict__ bias,
                                                              const float *__restrict__ res, long long n, int C) {
@@ -204,6 +282,41 @@ extern "C" int dib_fpn_topdown_merge_nhwc(float *x_dev, const float *bias_dev, c
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   hipLaunchKernelGGL(topdown_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)x_dev, (const float4 *)bias_dev,
                      (const float4 *)top_dev, H, W, Ht, Wt, C / 4, (float)Ht / (float)H, (float)Wt / (float)W, n4);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
+
+// out[N, Ho, Wo, C] = max_pool2d(relu(x[N, H, W, C] + bias[C]), 3, stride 2, padding 1), Ho = (H - 1) / 2 + 1; arg: one
+// unsigned short per 4 output channels (4-bit window position of the winner per channel, 15 = no gradient).  C % 4 == 0.
+extern "C" int dib_stem_pool_forward(const float *x_dev, const float *bias_dev, float *out_dev, unsigned short *arg_dev, int N, int H, int W,
+                                     int C, void *stream) {
+  if (N < 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) != 0) { set_error("dib_stem_pool_forward: bad shape (C %% 4 == 0)"); return DIB_EINVAL; }
+  if (N == 0) return DIB_OK;
+  if (!x_dev || !bias_dev || !out_dev || !arg_dev) { set_error("dib_stem_pool_forward: null pointer"); return DIB_EINVAL; }
+  if ((((uintptr_t)x_dev | (uintptr_t)bias_dev | (uintptr_t)out_dev) & 15) != 0) { set_error("dib_stem_pool_forward: tensors must be 16-byte aligned"); return DIB_EINVAL; }
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long n4 = (long long)N * Ho * Wo * (C / 4);
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)x_dev, (const float4 *)bias_dev,
+                     (float4 *)out_dev, arg_dev, H, W, Ho, Wo, C / 4, n4);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
+
+// grad_in[N, H, W, C] from grad_out[N, Ho, Wo, C] and the forward pass's arg.
+extern "C" int dib_stem_pool_backward(const float *grad_out_dev, const unsigned short *arg_dev, float *grad_in_dev, int N, int H, int W, int C,
+                                      void *stream) {
+  if (N < 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) != 0) { set_error("dib_stem_pool_backward: bad shape (C %% 4 == 0)"); return DIB_EINVAL; }
+  if (N == 0) return DIB_OK;
+  if (!grad_out_dev || !arg_dev || !grad_in_dev) { set_error("dib_stem_pool_backward: null pointer"); return DIB_EINVAL; }
+  if ((((uintptr_t)grad_out_dev | (uintptr_t)grad_in_dev) & 15) != 0) { set_error("dib_stem_pool_backward: tensors must be 16-byte aligned"); return DIB_EINVAL; }
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long n4 = (long long)N * H * W * (C / 4);
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)grad_out_dev, arg_dev,
+                     (float4 *)grad_in_dev, H, W, Ho, Wo, C / 4, n4);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }

@@ -387,6 +387,56 @@ class Bottleneck(nn.Module):
         return conv_bn(out, self.conv3, self.bn3, relu=True, residual=idt)
 
 
+FUSE_STEM_POOL = True     # stem: folded conv1 -> (bias + ReLU + 3x3/2 max-pool) as one pass
+
+
+class _StemPool(torch.autograd.Function):
+    """max_pool2d(relu(x + bias), 3, stride 2, padding 1) of a channels-last convolution output in one pass
+    (dib_stem_pool_forward); the backward pass rebuilds the dense gradient of x from the pooled gradient and 4 bits per pooled
+    element (dib_stem_pool_backward) -- ATen's max-pool backward and the ReLU backward in one."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        from .. import _lib
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        arg = torch.empty((N * Ho * Wo * (C // 4),), dtype=torch.int16, device=x.device)
+        _lib.check(_lib.lib().dib_stem_pool_forward(x.data_ptr(), bias.data_ptr(), out.data_ptr(), arg.data_ptr(), N, H, W, C,
+                                                    torch.cuda.current_stream().cuda_stream))
+        ctx.shape = (N, C, H, W)
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib
+        (arg,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        if not g.is_contiguous(memory_format=torch.channels_last) or (g.data_ptr() & 15):
+            g = g.clone(memory_format=torch.channels_last)
+        gx = torch.empty((N, C, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().dib_stem_pool_backward(g.data_ptr(), arg.data_ptr(), gx.data_ptr(), N, H, W, C,
+                                                     torch.cuda.current_stream().cuda_stream))
+        return gx, (gx.sum(dim=(0, 2, 3)) if ctx.needs_input_grad[1] else None)
+
+
+def stem(x, conv, bn):
+    """max_pool2d(relu(bn(conv(x))), 3, stride=2, padding=1): the ResNet stem."""
+    if (FUSE_STEM_POOL and FUSE_EPILOGUE and FOLD_FROZEN_BN and isinstance(bn, FrozenBatchNorm2d) and conv.bias is None and x.is_cuda
+            and x.dtype == torch.float32 and conv.out_channels % 4 == 0):
+        if torch.is_grad_enabled() and conv.weight.requires_grad:
+            scale, shift = bn.affine()
+            weight = conv.weight * scale.reshape(-1, 1, 1, 1)
+        else:
+            weight, shift = _folded(conv, bn)
+        y = conv1x1(x, weight, None, conv)
+        if y.is_contiguous(memory_format=torch.channels_last) and not (y.data_ptr() & 15):
+            return _StemPool.apply(y, shift.contiguous())
+        return F.max_pool2d(bias_act(y, shift, None, True), 3, stride=2, padding=1)
+    return F.max_pool2d(conv_bn(x, conv, bn, relu=True), 3, stride=2, padding=1)
+
+
 class ResNet50Body(nn.Module):
     def __init__(self, norm_layer=FrozenBatchNorm2d):
         super().__init__()
@@ -409,7 +459,7 @@ class ResNet50Body(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = F.max_pool2d(conv_bn(x, self.conv1, self.bn1, relu=True), 3, stride=2, padding=1)
+        x = stem(x, self.conv1, self.bn1)
         c2 = self.layer1(x)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -211,6 +211,14 @@ int dib_scatter_add_nhwc(float *a_dev, const float *b_dev, int N, int H, int W, 
  * add that reads it back. */
 int dib_fpn_topdown_merge_nhwc(float *x_dev, const float *bias_dev, const float *top_dev, int N, int H, int W, int Ht, int Wt, int C,
                                void *stream);
+/* ResNet stem (torchvision resnet50: conv1 -> bn1 -> relu -> maxpool(3, stride 2, padding 1)) behind the folded convolution:
+ * out[N, Ho, Wo, C] = max_pool2d(relu(x + bias)), Ho = (H - 1) / 2 + 1, in one pass; arg_dev: one unsigned short per 4 output
+ * channels (4-bit window position of the winner, 15 = no gradient).  The backward pass turns grad_out + arg into the dense
+ * gradient of x (max-pool backward and ReLU backward in one pass).  Channels-last fp32, C % 4 == 0, 16-byte aligned. */
+int dib_stem_pool_forward(const float *x_dev, const float *bias_dev, float *out_dev, unsigned short *arg_dev, int N, int H, int W, int C,
+                          void *stream);
+int dib_stem_pool_backward(const float *grad_out_dev, const unsigned short *arg_dev, float *grad_in_dev, int N, int H, int W, int C,
+                           void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Post-blur corruption chain of manual_blur (reference models/blur_functions.py:72-81) in one pass:

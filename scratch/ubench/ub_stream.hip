@@ -51,6 +51,33 @@ __global__ __launch_bounds__(256) void k_two32(float4 *x, const float4 *bias, un
               mask[j] = (unsigned char)((u.x > 0.f ? 1 : 0) | (u.y > 0.f ? 2 : 0) | (u.z > 0.f ? 4 : 0) | (u.w > 0.f ? 8 : 0)); }
 }
 
+// ATen's elementwise shape: 128 threads, 4 scalar elements per thread, strided by the block (every load a coalesced 512 B per wave)
+template <int VEC>   // VEC floats per access (1, 2 or 4), 4 accesses per thread
+__global__ __launch_bounds__(128) void k_unroll4(float *x, const float *bias, unsigned n, unsigned C) {
+  const unsigned base = blockIdx.x * (128u * 4u * VEC) + threadIdx.x * VEC;
+  float v[4][VEC];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned i = base + u * 128u * VEC;
+    if (i < n) {
+      if (VEC == 4) { const float4 t = *reinterpret_cast<const float4 *>(x + i); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
+      else if (VEC == 2) { const float2 t = *reinterpret_cast<const float2 *>(x + i); v[u][0] = t.x; v[u][1] = t.y; }
+      else v[u][0] = x[i];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned i = base + u * 128u * VEC;
+    if (i < n) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[u][k] = fmaxf(v[u][k] + bias[(i + k) % C], 0.f);
+      if (VEC == 4) *reinterpret_cast<float4 *>(x + i) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+      else if (VEC == 2) *reinterpret_cast<float2 *>(x + i) = make_float2(v[u][0], v[u][1]);
+      else x[i] = v[u][0];
+    }
+  }
+}
+
 int main() {
   const long long n = 8ll * 256 * 200 * 336, n4 = n / 4; const int C4 = 64;
   float4 *x, *bias; unsigned char *mask;
@@ -70,6 +97,9 @@ int main() {
     TIME("stride32 cap 32768, mask", [&] { hipLaunchKernelGGL(k_stride32<true>, dim3(32768), dim3(256), 0, 0, x, bias, (unsigned)n4, C4, mask); });
     TIME("one float4 per thread, no mask", [&] { hipLaunchKernelGGL(k_one32<false>, dim3(full), dim3(256), 0, 0, x, bias, (unsigned)n4, C4, mask); });
     TIME("one float4 per thread, mask", [&] { hipLaunchKernelGGL(k_one32<true>, dim3(full), dim3(256), 0, 0, x, bias, (unsigned)n4, C4, mask); });
+    TIME("128 thr x 4 x float (ATen shape)", [&] { hipLaunchKernelGGL(k_unroll4<1>, dim3((unsigned)((n + 511) / 512)), dim3(128), 0, 0, (float *)x, (const float *)bias, (unsigned)n, 256u); });
+    TIME("128 thr x 4 x float2", [&] { hipLaunchKernelGGL(k_unroll4<2>, dim3((unsigned)((n + 1023) / 1024)), dim3(128), 0, 0, (float *)x, (const float *)bias, (unsigned)n, 256u); });
+    TIME("128 thr x 4 x float4", [&] { hipLaunchKernelGGL(k_unroll4<4>, dim3((unsigned)((n + 2047) / 2048)), dim3(128), 0, 0, (float *)x, (const float *)bias, (unsigned)n, 256u); });
     TIME("two float4 per thread, no mask", [&] { hipLaunchKernelGGL(k_two32<false>, dim3((full + 1) / 2), dim3(256), 0, 0, x, bias, (unsigned)n4, C4, mask); });
     TIME("two float4 per thread, mask", [&] { hipLaunchKernelGGL(k_two32<true>, dim3((full + 1) / 2), dim3(256), 0, 0, x, bias, (unsigned)n4, C4, mask); });
   }

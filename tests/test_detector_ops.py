@@ -579,3 +579,53 @@ def test_rpn_filter_per_level_sets_equal_torchvisions_batched_nms_on_cpu():
 @pytest.mark.gpu
 def test_rpn_filter_per_level_sets_equal_torchvisions_batched_nms_on_gpu():
     _check_rpn_filter(torch.device("cuda"))
+
+
+@pytest.mark.gpu
+def test_stem_bias_relu_maxpool_in_one_pass_equals_the_three_torch_ops():
+    """dib_stem_pool_forward / _backward against bias add -> relu -> max_pool2d(3, 2, 1) and autograd through them: pooled
+    values bit for bit (even / odd sizes, borders), the dense gradient of the convolution output bit for bit where one window
+    claims a pixel and to one rounding where up to four do, ties at zero (no gradient) and positive ties (first in row-major
+    window order, ATen's rule)."""
+    from detectinblur_amd.models import backbone as B
+    F = torch.nn.functional
+    torch.manual_seed(17)
+    for (N, C, H, W) in ((2, 64, 40, 56), (1, 64, 37, 51), (3, 8, 9, 12), (1, 4, 1, 1), (1, 4, 2, 5)):
+        x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+        if H > 2 and W > 2:                                       # exact ties between neighbours (positive and negative)
+            x[:, :, 1::3, 1::4] = x[:, :, 0::3, 0::4][:, :, :x[:, :, 1::3, 1::4].shape[2], :x[:, :, 1::3, 1::4].shape[3]]
+        bias = torch.randn(C, device="cuda")
+        xa = x.clone().requires_grad_(True)
+        want = F.max_pool2d(torch.relu(xa + bias.reshape(1, -1, 1, 1)), 3, stride=2, padding=1)
+        g = torch.randn_like(want)
+        want.backward(g)
+        xb = x.clone().requires_grad_(True)
+        got = B._StemPool.apply(xb * 1.0, bias)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(got, want.detach())
+        got.backward(g)
+        assert torch.allclose(xb.grad, xa.grad, rtol=1e-6, atol=1e-6), (N, C, H, W, float((xb.grad - xa.grad).abs().max()))
+    # through the module: the body with and without the fused stem
+    body = B.ResNet50Body().cuda()
+    img = torch.randn(2, 3, 96, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = {}
+    try:
+        for flag in (True, False):
+            B.FUSE_STEM_POOL = flag
+            body.zero_grad()
+            feats = body(img)
+            sum((f * f).mean() for f in feats).backward()
+            res[flag] = ([f.detach().clone() for f in feats], body.conv1.weight.grad.clone())
+    finally:
+        B.FUSE_STEM_POOL = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm())            # 50 random-init layers behind the stem
+    assert float((res[True][1] - res[False][1]).norm()) <= 2e-3 * float(res[False][1].norm())
+    try:                                                                   # the stem itself: bit for bit
+        with torch.no_grad():
+            fused = B.stem(img, body.conv1, body.bn1)
+            B.FUSE_STEM_POOL = False
+            plain = B.stem(img, body.conv1, body.bn1)
+    finally:
+        B.FUSE_STEM_POOL = True
+    assert torch.equal(fused, plain)
