@@ -104,75 +104,79 @@ __global__ __launch_bounds__(256) void topdown_merge_kernel(float4 *__restrict__
 // are ATen's (max_pool2d: first maximum in row-major window order).
 __global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ bias,
                                                            float4 *__restrict__ out, unsigned short *__restrict__ arg, int H, int W,
-                                                           int Ho, int Wo, int C4, long long n4) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4);
-    long long p = i / C4;
-    const int ow = (int)(p % Wo);
-    p /= Wo;
-    const int oh = (int)(p % Ho);
-    const long long n = p / Ho;
-    const float4 b = bias[c];
-    const float ninf = -__builtin_inff();
-    float4 m = make_float4(ninf, ninf, ninf, ninf);
-    unsigned ax = 15, ay = 15, az = 15, aw = 15;
+                                                           int Ho, int Wo, int C4) {
+  // grid: x over the Wo * C4 float4 of one pooled row, y = pooled row, z = image (no 64-bit divisions on the way to an address)
+  const unsigned col = blockIdx.x * 256u + threadIdx.x;
+  if (col >= (unsigned)(Wo * C4)) return;
+  const int ow = (int)(col / (unsigned)C4), c = (int)(col % (unsigned)C4), oh = blockIdx.y;
+  const size_t n = blockIdx.z;
+  const float4 b = bias[c];
+  const float ninf = -__builtin_inff();
+  float4 m = make_float4(ninf, ninf, ninf, ninf);
+  unsigned ax = 15, ay = 15, az = 15, aw = 15;
+  // all nine loads are issued before the first comparison (clamped addresses, out-of-range positions replaced by -inf): one
+  // memory round trip per thread instead of up to nine dependent ones
+  float4 v[9];
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int h = oh * 2 - 1 + dh;
-      if (h < 0 || h >= H) continue;
-#pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        const int w = ow * 2 - 1 + dw;
-        if (w < 0 || w >= W) continue;
-        float4 v = x[((n * H + h) * W + w) * C4 + c];
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        const unsigned k = dh * 3 + dw;
-        if (v.x > m.x) { m.x = v.x; ax = k; }
-        if (v.y > m.y) { m.y = v.y; ay = k; }
-        if (v.z > m.z) { m.z = v.z; az = k; }
-        if (v.w > m.w) { m.w = v.w; aw = k; }
-      }
-    }
-    if (!(m.x > 0.f)) { m.x = 0.f; ax = 15; }
-    if (!(m.y > 0.f)) { m.y = 0.f; ay = 15; }
-    if (!(m.z > 0.f)) { m.z = 0.f; az = 15; }
-    if (!(m.w > 0.f)) { m.w = 0.f; aw = 15; }
-    out[i] = m;
-    arg[i] = (unsigned short)(ax | (ay << 4) | (az << 8) | (aw << 12));
+  for (int k = 0; k < 9; ++k) {
+    const int h = oh * 2 - 1 + k / 3, w = ow * 2 - 1 + k % 3;
+    const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+    v[k] = x[((n * H + hc) * W + wc) * C4 + c];
   }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int h = oh * 2 - 1 + k / 3, w = ow * 2 - 1 + k % 3;
+    const bool in = h >= 0 && h < H && w >= 0 && w < W;
+    const float vx = in ? v[k].x + b.x : ninf, vy = in ? v[k].y + b.y : ninf, vz = in ? v[k].z + b.z : ninf, vw = in ? v[k].w + b.w : ninf;
+    if (vx > m.x) { m.x = vx; ax = k; }
+    if (vy > m.y) { m.y = vy; ay = k; }
+    if (vz > m.z) { m.z = vz; az = k; }
+    if (vw > m.w) { m.w = vw; aw = k; }
+  }
+  if (!(m.x > 0.f)) { m.x = 0.f; ax = 15; }
+  if (!(m.y > 0.f)) { m.y = 0.f; ay = 15; }
+  if (!(m.z > 0.f)) { m.z = 0.f; az = 15; }
+  if (!(m.w > 0.f)) { m.w = 0.f; aw = 15; }
+  const size_t i = ((n * Ho + oh) * Wo) * C4 + col;
+  out[i] = m;
+  arg[i] = (unsigned short)(ax | (ay << 4) | (az << 8) | (aw << 12));
 }
 
 // Its backward: the gradient of the convolution output, dense (every input pixel belongs to at most 2 x 2 windows; it takes the
 // pooled gradient of those whose recorded winner it is).  One pass: pooled gradient + 2 bytes per 4 pooled elements in,
 // full-size gradient out -- instead of ATen's max-pool backward plus the ReLU mask pass.
 __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const float4 *__restrict__ g_out, const unsigned short *__restrict__ arg,
-                                                           float4 *__restrict__ g_in, int H, int W, int Ho, int Wo, int C4, long long n4) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4);
-    long long p = i / C4;
-    const int w = (int)(p % W);
-    p /= W;
-    const int h = (int)(p % H);
-    const long long n = p / H;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int oh0 = h >> 1, oh1 = (h + 1) >> 1, ow0 = w >> 1, ow1 = (w + 1) >> 1;     // windows oh with 2 oh - 1 <= h <= 2 oh + 1
-    for (int oh = oh0; oh <= oh1; ++oh) {
-      if (oh >= Ho) continue;
-      const unsigned dh = (unsigned)(h - (oh * 2 - 1));
-      for (int ow = ow0; ow <= ow1; ++ow) {
-        if (ow >= Wo) continue;
-        const unsigned k = dh * 3 + (unsigned)(w - (ow * 2 - 1));
-        const long long j = ((n * Ho + oh) * Wo + ow) * C4 + c;
-        const unsigned a = arg[j];
-        const float4 go = g_out[j];
-        if ((a & 15u) == k) g.x += go.x;
-        if (((a >> 4) & 15u) == k) g.y += go.y;
-        if (((a >> 8) & 15u) == k) g.z += go.z;
-        if ((a >> 12) == k) g.w += go.w;
-      }
-    }
-    g_in[i] = g;
+                                                           float4 *__restrict__ g_in, int H, int W, int Ho, int Wo, int C4) {
+  // grid: x over the W * C4 float4 of one input row, y = input row, z = image
+  const unsigned col = blockIdx.x * 256u + threadIdx.x;
+  if (col >= (unsigned)(W * C4)) return;
+  const int w = (int)(col / (unsigned)C4), c = (int)(col % (unsigned)C4), h = blockIdx.y;
+  const size_t n = blockIdx.z;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the (at most) 2 x 2 windows that contain (h, w): oh in {h >> 1, (h + 1) >> 1}, likewise ow; all loads first, then the
+  // selection -- one memory round trip per thread
+  const int ohs[2] = {h >> 1, (h + 1) >> 1}, ows[2] = {w >> 1, (w + 1) >> 1};
+  unsigned a[4];
+  float4 go[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int oh = min(ohs[q >> 1], Ho - 1), ow = min(ows[q & 1], Wo - 1);
+    const size_t j = ((n * Ho + oh) * Wo + ow) * C4 + c;
+    a[q] = arg[j];
+    go[q] = g_out[j];
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int oh = ohs[q >> 1], ow = ows[q & 1];
+    // a window counts once: the second candidate equals the first for even h (w), and must lie inside the pooled image
+    const bool use = oh < Ho && ow < Wo && ((q >> 1) == 0 || ohs[1] != ohs[0]) && ((q & 1) == 0 || ows[1] != ows[0]);
+    const unsigned k = use ? (unsigned)(h - (oh * 2 - 1)) * 3u + (unsigned)(w - (ow * 2 - 1)) : 14u;      // 14: never recorded
+    if ((a[q] & 15u) == k) g.x += go[q].x;
+    if (((a[q] >> 4) & 15u) == k) g.y += go[q].y;
+    if (((a[q] >> 8) & 15u) == k) g.z += go[q].z;
+    if ((a[q] >> 12) == k) g.w += go[q].w;
+  }
+  g_in[((n * H + h) * W) * C4 + col] = g;
 }
 
 template <bool RES, bool RELU>
@@ -295,11 +299,9 @@ extern "C" int dib_stem_pool_forward(const float *x_dev, const float *bias_dev, 
   if (!x_dev || !bias_dev || !out_dev || !arg_dev) { set_error("dib_stem_pool_forward: null pointer"); return DIB_EINVAL; }
   if ((((uintptr_t)x_dev | (uintptr_t)bias_dev | (uintptr_t)out_dev) & 15) != 0) { set_error("dib_stem_pool_forward: tensors must be 16-byte aligned"); return DIB_EINVAL; }
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const long long n4 = (long long)N * Ho * Wo * (C / 4);
-  long long blocks = (n4 + 255) / 256;
-  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
-  hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)x_dev, (const float4 *)bias_dev,
-                     (float4 *)out_dev, arg_dev, H, W, Ho, Wo, C / 4, n4);
+  if (Ho > 65535 || N > 65535) { set_error("dib_stem_pool_forward: at most 65535 pooled rows and images per call"); return DIB_ESHAPE; }
+  hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3((unsigned)((Wo * (C / 4) + 255) / 256), (unsigned)Ho, (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                     (const float4 *)x_dev, (const float4 *)bias_dev, (float4 *)out_dev, arg_dev, H, W, Ho, Wo, C / 4);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }
@@ -312,11 +314,9 @@ extern "C" int dib_stem_pool_backward(const float *grad_out_dev, const unsigned 
   if (!grad_out_dev || !arg_dev || !grad_in_dev) { set_error("dib_stem_pool_backward: null pointer"); return DIB_EINVAL; }
   if ((((uintptr_t)grad_out_dev | (uintptr_t)grad_in_dev) & 15) != 0) { set_error("dib_stem_pool_backward: tensors must be 16-byte aligned"); return DIB_EINVAL; }
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const long long n4 = (long long)N * H * W * (C / 4);
-  long long blocks = (n4 + 255) / 256;
-  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
-  hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)grad_out_dev, arg_dev,
-                     (float4 *)grad_in_dev, H, W, Ho, Wo, C / 4, n4);
+  if (H > 65535 || N > 65535) { set_error("dib_stem_pool_backward: at most 65535 rows and images per call"); return DIB_ESHAPE; }
+  hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3((unsigned)((W * (C / 4) + 255) / 256), (unsigned)H, (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                     (const float4 *)grad_out_dev, arg_dev, (float4 *)grad_in_dev, H, W, Ho, Wo, C / 4);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }
