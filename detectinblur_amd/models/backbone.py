@@ -164,11 +164,53 @@ def _as_planar(x, conv):
     return not torch.is_grad_enabled() and conv.in_channels >= 128 and x.shape[0] * ho * wo <= 16800
 
 
+class _Gemm1x1(torch.autograd.Function):
+    """A 1x1 stride-1 convolution of a channels-last tensor as GEMMs on the same memory (hipBLASLt), returning a tensor of its
+    OWN -- not the permuted view `F.linear(x.permute(...)).permute(...)` gives.  The difference matters to the in-place
+    epilogue behind it: modifying a view in place makes autograd rebuild the gradient through CopySlices / AsStridedBackward,
+    four full-size copies per convolution in the backward pass (12 x 69 MB per train step for layer4's three 512 -> 2048
+    convolutions: 1 ms)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, Ci, H, W = x.shape
+        Co = weight.shape[0]
+        out = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        xf, wf = x.permute(0, 2, 3, 1).reshape(-1, Ci), weight.reshape(Co, Ci)
+        of = out.permute(0, 2, 3, 1).view(-1, Co)
+        if bias is None:
+            torch.mm(xf, wf.t(), out=of)
+        else:
+            torch.addmm(bias, xf, wf.t(), out=of)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        N, Ci, H, W = x.shape
+        Co = weight.shape[0]
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        gf = g.permute(0, 2, 3, 1).reshape(-1, Co)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(gf, weight.reshape(Co, Ci)).view(N, H, W, Ci).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(gf.t(), x.permute(0, 2, 3, 1).reshape(-1, Ci)).view(weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gf.sum(0)
+        return dx, dw, db
+
+
 def conv1x1(x, weight, bias, conv):
     """F.conv2d for every convolution, with two shape-based detours: the same contraction through F.linear for 1x1 / stride 1 /
     small M / wide channels, and planar (NCHW) tensors around small-M wide 3x3 convolutions.  Output always channels-last
     when the input is."""
     if _as_gemm(x, conv):
+        if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+            return _Gemm1x1.apply(x, weight, bias)
         return F.linear(x.permute(0, 2, 3, 1), weight.reshape(conv.out_channels, conv.in_channels), bias).permute(0, 3, 1, 2)
     if _as_planar(x, conv):
         y = F.conv2d(x.contiguous(), weight.contiguous(), bias, conv.stride, conv.padding, conv.dilation, conv.groups)
