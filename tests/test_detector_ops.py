@@ -545,9 +545,17 @@ def _reference_filter(props, obj, counts, pre, post, size_wh, thresh, min_size):
     return b[keep], s[keep]
 
 
-def _check_rpn_filter(device):
+def _canon(boxes, scores):
+    """rows [score, box] ordered by score (descending) and then by the box coordinates: two proposals with the same score
+    (40 seeds of random logits produce one such pair) may come out in either order."""
+    rows = torch.cat([scores[:, None], boxes], dim=1).cpu().numpy()
+    order = np.lexsort((rows[:, 4], rows[:, 3], rows[:, 2], rows[:, 1], -rows[:, 0]))
+    return torch.from_numpy(rows[order])
+
+
+def _check_rpn_filter(device, seed=31):
     from detectinblur_amd.models import rpn as R
-    torch.manual_seed(31)
+    torch.manual_seed(seed)
     rpn = R.RegionProposalNetwork(None, None, 0.7, 0.3, 256, 0.5, dict(training=300, testing=150), dict(training=200, testing=100), 0.7)
     counts = [1200, 300, 75, 27]
     N, A = 3, sum(counts)
@@ -565,15 +573,17 @@ def _check_rpn_filter(device):
         for i in range(N):
             wb, ws = _reference_filter(props[i], obj.view(N, A)[i], counts, pre, post, (float(sizes[i][1]), float(sizes[i][0])), 0.7, rpn.min_size)
             assert boxes[i].shape == wb.shape and 0 < wb.shape[0] <= post, (training, i, boxes[i].shape, wb.shape)
-            assert torch.equal(scores[i], ws) and torch.equal(boxes[i], wb)
-            assert int(ok[i].sum()) == wb.shape[0] and torch.equal(pb[i][ok[i]], wb)
+            assert torch.equal(scores[i], ws)                       # same scores in the same (descending) order
+            assert torch.equal(_canon(boxes[i], scores[i]), _canon(wb, ws))      # boxes: up to the order among EQUAL scores
+            assert int(ok[i].sum()) == wb.shape[0] and torch.equal(_canon(pb[i][ok[i]], scores[i]), _canon(wb, ws))
 
 
 def test_rpn_filter_per_level_sets_equal_torchvisions_batched_nms_on_cpu():
     """RegionProposalNetwork._filter (one NMS set per image and level, survivors ranked by a top-k) against the plain
     restatement of torchvision's filter_proposals (one batched NMS per image over all levels): same boxes, same scores,
     same order, in training and in inference mode, ragged levels, degenerate boxes, unpadded and padded forms."""
-    _check_rpn_filter(torch.device("cpu"))
+    for seed in (31, 1039, 7):                                   # 1039: two proposals with exactly equal scores
+        _check_rpn_filter(torch.device("cpu"), seed)
 
 
 @pytest.mark.gpu
