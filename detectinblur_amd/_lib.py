@@ -120,9 +120,20 @@ def check(code):
         raise DibError(code, lib().dib_last_error().decode("utf-8", "replace"))
 
 
+_INT_ARRAYS, _PTR_ARRAYS = {}, {}      # ctypes array TYPES by length (building the type is most of a small array's cost)
+
+
 def int_array(values):
-    return (ctypes.c_int * len(values))(*values)
+    n = len(values)
+    t = _INT_ARRAYS.get(n)
+    if t is None:
+        t = _INT_ARRAYS[n] = ctypes.c_int * n
+    return t(*values)
 
 
 def ptr_array(values):
-    return (ctypes.c_void_p * len(values))(*values)
+    n = len(values)
+    t = _PTR_ARRAYS.get(n)
+    if t is None:
+        t = _PTR_ARRAYS[n] = ctypes.c_void_p * n
+    return t(*values)

@@ -27,8 +27,14 @@ def _require_cuda(t, what):
         raise RuntimeError("%s must live on the GPU: detectinblur_amd has no CPU path" % what)
 
 
+_TABLE_WORDS = {}
+
+
 def table_words(K):
-    return _lib.lib().dib_tap_table_bytes(K) // 4
+    w = _TABLE_WORDS.get(K)
+    if w is None:
+        w = _TABLE_WORDS[K] = _lib.lib().dib_tap_table_bytes(K) // 4
+    return w
 
 
 class TapTables:
@@ -39,7 +45,7 @@ class TapTables:
         self.words = table_words(K)
         if self.words == 0:
             raise ValueError("PSF must be 128 or 256 wide, got %d" % K)
-        self.buf = torch.empty(_lib.lib().dib_tap_tables_bytes(K, count) // 4, dtype=torch.int32, device=device)
+        self.buf = torch.empty(self.words * count, dtype=torch.int32, device=device)     # == dib_tap_tables_bytes(K, count) / 4
 
     def ptr(self, i=0):
         return self.buf.data_ptr() + 4 * self.words * i
@@ -82,9 +88,11 @@ def compact_psfs(psfs, normalize):
         K, dt = first.shape[0], first.dtype
         if dt not in _DT:
             raise TypeError("PSF dtype %s not supported (float16 / float32)" % dt)
-        keep, ptrs, want = [], [], (K, K)
+        keep, ptrs, want = [], [], first.shape
+        if first.dim() != 2 or want[1] != K:
+            raise ValueError("all PSFs of one call must be K x K CUDA tensors of one dtype")
         for p in psfs:
-            if tuple(p.shape) != want or p.dtype != dt or not p.is_cuda:
+            if p.shape != want or p.dtype != dt or not p.is_cuda:
                 raise ValueError("all PSFs of one call must be K x K CUDA tensors of one dtype")
             if not p.is_contiguous():
                 p = p.contiguous()
@@ -126,6 +134,8 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
     dt, dev = first.dtype, first.device
     if dt not in _DT:
         raise TypeError("image dtype %s not supported (float16 / float32)" % dt)
+    # This loop is on the host's critical path (the eager step is two launches and ~35 us of interpreter): one pass with as
+    # few tensor-attribute calls per image as the checks allow.
     ins_p, outs_p, Cs, Hs, Ws = [None] * n, [None] * n, [0] * n, [0] * n, [0] * n
     srcs, uniform, shp = [], True, first.shape
     for i in act:
@@ -136,23 +146,30 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
             raise TypeError("all images of one call must share a dtype")
         if not img.is_contiguous():
             img = img.contiguous()
-        nd = img.dim()
+        sh = img.shape
+        if sh != shp:
+            uniform = False
+        nd = len(sh)
         if nd == 3:
-            Cs[i], Hs[i], Ws[i] = img.shape
+            Cs[i], Hs[i], Ws[i] = sh
         elif nd == 2:
             Cs[i] = 1
-            Hs[i], Ws[i] = img.shape
+            Hs[i], Ws[i] = sh
         else:
-            raise ValueError("image must be C x H x W, got %s" % (tuple(img.shape),))
-        uniform = uniform and img.shape == shp
+            raise ValueError("image must be C x H x W, got %s" % (tuple(sh),))
         ins_p[i] = img.data_ptr()
         srcs.append(img)      # keeps a .contiguous() copy alive until the launch below
     if uniform and len(act) > 1:
         block = torch.empty((len(act),) + tuple(shp), dtype=dt, device=dev)
         base, step = block.data_ptr(), block.stride(0) * block.element_size()
-        for k, (i, o) in enumerate(zip(act, block.unbind(0))):
-            outs[i] = o
-            outs_p[i] = base + k * step
+        parts = block.unbind(0)
+        if len(act) == n:                      # nothing skipped: the outputs ARE the slices, in order
+            outs = list(parts)
+            outs_p = [base + k * step for k in range(n)]
+        else:
+            for k, i in enumerate(act):
+                outs[i] = parts[k]
+                outs_p[i] = base + k * step
     else:
         for i, src in zip(act, srcs):
             o = torch.empty_like(src)

