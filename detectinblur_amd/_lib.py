@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 
 DIB_F16, DIB_F32 = 0, 1
 DIB_ACC_BITEXACT, DIB_ACC_FP32, DIB_ACC_FMA16 = 0, 1, 2
-DIB_EINVAL, DIB_ESHAPE, DIB_EHIP, DIB_ENOT128 = -1, -2, -3, -4
+DIB_EINVAL, DIB_ESHAPE, DIB_EHIP, DIB_ENOT128, DIB_ECAPTURE = -1, -2, -3, -4, -5
+DIB_STEP_PSFS_COMPLETE = 1
 
 _lib = None
 
@@ -36,6 +37,10 @@ _SIGNATURES = {
     "dib_sparse_blur": (ctypes.c_int, [_c_void_pp, _c_void_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p]),
+    "dib_blur_step": (ctypes.c_int, [_c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     _c_void_pp, _c_void_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "dib_blur_step_release": (ctypes.c_int, []),
     "dib_normalize_pad": (ctypes.c_int, [_c_void_pp, ctypes.c_int, _c_int_p, _c_int_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p]),
@@ -109,7 +114,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.dib_abi_version() != 4:
+        if l.dib_abi_version() != 5:
             raise ImportError("libdib_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -121,21 +121,21 @@ def compact_psfs(psfs, normalize):
     return tabs
 
 
-def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
-    """images: list of C x H x W (or H x W) tensors, all one dtype; table_index[i] < 0 skips image i.
-    Returns the list of outputs (new tensors for blurred entries, the input tensor otherwise).
-    When every blurred image has the same shape the outputs are slices of ONE allocation."""
+def _describe(images, table_index):
+    """The per-image arrays of dib_sparse_blur / dib_blur_step for `images` (table_index[i] < 0 skips image i), with the
+    outputs allocated: (outs, ins_p, outs_p, Cs, Hs, Ws, dtype, device, keep) or None when nothing is to be blurred.
+    When every blurred image has the same shape the outputs are slices of ONE allocation.
+    This loop is on the host's critical path (the eager step is ~15 us of interpreter in front of a 40 us kernel): one pass
+    with as few tensor-attribute calls per image as the checks allow."""
     n = len(images)
     outs = list(images)
     act = [i for i in range(n) if table_index[i] >= 0]
     if not act:
-        return outs
+        return None
     first = images[act[0]]
     dt, dev = first.dtype, first.device
     if dt not in _DT:
         raise TypeError("image dtype %s not supported (float16 / float32)" % dt)
-    # This loop is on the host's critical path (the eager step is two launches and ~35 us of interpreter): one pass with as
-    # few tensor-attribute calls per image as the checks allow.
     ins_p, outs_p, Cs, Hs, Ws = [None] * n, [None] * n, [0] * n, [0] * n, [0] * n
     srcs, uniform, shp = [], True, first.shape
     for i in act:
@@ -158,7 +158,7 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
         else:
             raise ValueError("image must be C x H x W, got %s" % (tuple(sh),))
         ins_p[i] = img.data_ptr()
-        srcs.append(img)      # keeps a .contiguous() copy alive until the launch below
+        srcs.append(img)      # keeps a .contiguous() copy alive until the launch
     if uniform and len(act) > 1:
         block = torch.empty((len(act),) + tuple(shp), dtype=dt, device=dev)
         base, step = block.data_ptr(), block.stride(0) * block.element_size()
@@ -175,11 +175,65 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
             o = torch.empty_like(src)
             outs[i] = o
             outs_p[i] = o.data_ptr()
+    return outs, ins_p, outs_p, Cs, Hs, Ws, dt, dev, srcs
+
+
+def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
+    """images: list of C x H x W (or H x W) tensors, all one dtype; table_index[i] < 0 skips image i.
+    Returns the list of outputs (new tensors for blurred entries, the input tensor otherwise)."""
+    d = _describe(images, table_index)
+    if d is None:
+        return list(images)
+    outs, ins_p, outs_p, Cs, Hs, Ws, dt, dev, _keep = d
     _await(tables)
     _lib.check(_lib.lib().dib_sparse_blur(_lib.ptr_array(ins_p), _lib.ptr_array(outs_p), _lib.int_array(Cs),
                                           _lib.int_array(Hs), _lib.int_array(Ws), _lib.int_array(table_index),
-                                          n, _DT[dt], tables.buf.data_ptr(), tables.count, tables.K, acc_mode,
+                                          len(images), _DT[dt], tables.buf.data_ptr(), tables.count, tables.K, acc_mode,
                                           _stream(dev)))
+    return outs
+
+
+def blur_step(images, table_index, psfs, normalize=True, acc_mode=_lib.DIB_ACC_BITEXACT, psfs_complete=False):
+    """compact_psfs(psfs) + sparse_blur(images, table_index, tables) behind ONE library call (dib_blur_step), the tables
+    in library-owned buffers (two per stream, alternating).  psfs: list of K x K CUDA tensors of one dtype, 16-byte
+    aligned and contiguous (anything else is copied first).  `psfs_complete`: the caller states that the PSF buffers are
+    complete right now (not the product of work still queued on the current stream): the compaction is then launched
+    without a barrier in front of it and overlaps the kernel queued before it -- the previous step's blur.  Under graph
+    capture the tables come from the capture's own pool and both launches are ordinary."""
+    d = _describe(images, table_index)
+    if d is None:
+        return list(images)
+    outs, ins_p, outs_p, Cs, Hs, Ws, dt, dev, _keep = d
+    first = psfs[0]
+    K, pdt, want = first.shape[0], first.dtype, first.shape
+    if pdt not in _DT:
+        raise TypeError("PSF dtype %s not supported (float16 / float32)" % pdt)
+    if len(want) != 2 or want[1] != K:
+        raise ValueError("all PSFs of one call must be K x K CUDA tensors of one dtype")
+    if table_words(K) == 0:
+        raise ValueError("PSF must be 128 or 256 wide, got %d" % K)
+    keep, ptrs = [], []
+    for p in psfs:
+        if p.shape != want or p.dtype != pdt or not p.is_cuda:
+            raise ValueError("all PSFs of one call must be K x K CUDA tensors of one dtype")
+        if not p.is_contiguous():
+            p = p.contiguous()
+            psfs_complete = False          # the copy was just queued on the current stream
+        a = p.data_ptr()
+        if a & 15:
+            p = p.clone()
+            a = p.data_ptr()
+            psfs_complete = False
+        keep.append(p)
+        ptrs.append(a)
+    l = _lib.lib()
+    args = (_lib.ptr_array(ptrs), _DT[pdt], len(ptrs), K, int(bool(normalize)), _lib.ptr_array(ins_p), _lib.ptr_array(outs_p),
+            _lib.int_array(Cs), _lib.int_array(Hs), _lib.int_array(Ws), _lib.int_array(table_index), len(images), _DT[dt], acc_mode)
+    rc = l.dib_blur_step(*args, None, _lib.DIB_STEP_PSFS_COMPLETE if psfs_complete else 0, _stream(dev))
+    if rc == _lib.DIB_ECAPTURE:            # the current stream is being captured: tables from the capture's pool
+        tabs = TapTables(K, len(ptrs), dev)
+        rc = l.dib_blur_step(*args, tabs.buf.data_ptr(), 0, _stream(dev))
+    _lib.check(rc)
     return outs
 
 

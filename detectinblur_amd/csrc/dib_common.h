@@ -57,6 +57,8 @@ __device__ inline int map_coord(int s, int n, int pa, int pb, int mode, bool &ze
 }
 
 void set_error(const char *fmt, ...);
+// dib_compact.hip: the launch behind dib_psf_compact_list; any_order = hipExtAnyOrderLaunch (see dib_step.hip)
+int compact_launch(const void *const *ptrs, int dtype, int B, int K, int normalize, int *tables, hipStream_t s, bool any_order);
 
 #define DIB_HIP_CHECK(expr)                                                          \
   do {                                                                               \

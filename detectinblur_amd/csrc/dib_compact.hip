@@ -12,6 +12,7 @@
 // (24 >= 2*11+2).  Order of the output taps = row-major, the order of torch.nonzero: every thread
 // owns K*K/1024 CONSECUTIVE elements, so thread order is element order.
 #include "dib_common.h"
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <vector>
 
@@ -418,8 +419,12 @@ extern "C" size_t dib_tap_tables_bytes(int K, int B) {
   return (size_t)dib::table_words(K) * B * sizeof(int);
 }
 
-static int launch_compact(const void *const *ptrs, int dtype, int B, int K, int normalize, int *tables, hipStream_t s) {
+// any_order: the launches carry hipExtAnyOrderLaunch -- no barrier in front of them, so they may start while the kernel queued before
+// them on the same stream is still running (dib_blur_step with DIB_STEP_PSFS_COMPLETE: the previous step's blur).  The next ordinary
+// launch on the stream still waits for them.
+int dib::compact_launch(const void *const *ptrs, int dtype, int B, int K, int normalize, int *tables, hipStream_t s, bool any_order) {
   const size_t stride = (size_t)dib::table_words(K);
+  const int lflags = any_order ? hipExtAnyOrderLaunch : 0;
   for (int b0 = 0; b0 < B; b0 += dib::MAX_BATCH) {
     dib::PsfPtrs pp;
     const int n = B - b0 < dib::MAX_BATCH ? B - b0 : dib::MAX_BATCH;
@@ -429,13 +434,16 @@ static int launch_compact(const void *const *ptrs, int dtype, int B, int K, int 
     }
     int *t = tables + (size_t)b0 * stride;
     const int flags = normalize ? 1 : 0;
-    if (dtype == DIB_F16 && K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 128>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
-    else if (dtype == DIB_F16) hipLaunchKernelGGL((dib::psf_compact_kernel<__half, 256>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
-    else if (K == 128) hipLaunchKernelGGL((dib::psf_compact_kernel<float, 128>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
-    else hipLaunchKernelGGL((dib::psf_compact_kernel<float, 256>), dim3(n), dim3(dib::CT), 0, s, pp, flags, t);
+    if (dtype == DIB_F16 && K == 128) hipExtLaunchKernelGGL((dib::psf_compact_kernel<__half, 128>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);
+    else if (dtype == DIB_F16) hipExtLaunchKernelGGL((dib::psf_compact_kernel<__half, 256>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);
+    else if (K == 128) hipExtLaunchKernelGGL((dib::psf_compact_kernel<float, 128>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);
+    else hipExtLaunchKernelGGL((dib::psf_compact_kernel<float, 256>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);
   }
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
+}
+static int launch_compact(const void *const *ptrs, int dtype, int B, int K, int normalize, int *tables, hipStream_t s) {
+  return dib::compact_launch(ptrs, dtype, B, K, normalize, tables, s, false);
 }
 
 static int check_compact_args(const void *p, void *tables_dev, int dtype, int B, int K) {

@@ -1,0 +1,97 @@
+// One C entry point per blur step: tap compaction + sparse correlation of a whole batch behind ONE call
+// (reference models/blur_functions.py:92-100, `blur_image_list`: `psf / psf.sum()` + `manual_blur` per image).
+//
+// Why it exists: one call instead of two for the reference's one function, and the place where overlapping the compaction
+// (8 workgroups, a 5-6 us latency chain that depends on nothing but the PSFs) with the PREVIOUS step's blur was tried:
+//   * side stream + events (compaction on a library stream, hipEventRecord / hipStreamWaitEvent around it): 47.4 us per
+//     step against 44.3 for the plain serial pair -- on this runtime every event call costs the host 4-5 us and the
+//     cross-queue dependency ~3 us of GPU time (scratch/t_step_cost.py, profiles/r4_step_cost.txt);
+//   * DIB_STEP_PSFS_COMPLETE -> the compaction launched with hipExtAnyOrderLaunch (no barrier bit in front of it, so the
+//     command processor could start it while the kernel queued before it on the same stream still runs; the step's own blur
+//     is an ordinary launch and waits for everything in front of it).  This is what the flag does today.  The HIP runtime
+//     bundled with torch 2.10+rocm7.0 keeps the barrier anyway: 44.3 us with and without the flag.  The flag stays as a
+//     hint that costs nothing and is correct by construction (below); a runtime that honours it gets the overlap.
+//
+// Tables live in TWO buffers per (device, stream) owned by this file (the one exception to include/dib.h's "no entry
+// point allocates device memory"; grown to the largest batch seen, freed by dib_blur_step_release), used alternately:
+// compact(n+1) writes the buffer blur(n-1) read, and blur(n-1) is complete before blur(n) -- which precedes compact(n+1) in
+// the queue -- starts.  While the stream is being captured into a HIP graph the buffers are NOT used (a replay would
+// write them behind this bookkeeping's back): the caller passes its own table buffer and both launches are ordinary.
+#include "dib_common.h"
+#include <mutex>
+#include <unordered_map>
+
+using namespace dib;
+
+namespace {
+struct Slot {
+  int *buf = nullptr;
+  size_t bytes = 0;
+};
+
+struct StepState {
+  Slot slot[2];
+  unsigned next = 0;
+};
+
+std::mutex g_step_mutex;
+// keyed by (device, stream handle).  A handle reused by a later hipStreamCreate keeps its buffers; steps still in flight on
+// a destroyed stream are the caller's bug, as with any other buffer.
+std::unordered_map<unsigned long long, StepState> g_step;
+
+unsigned long long key_of(int dev, hipStream_t s) { return ((unsigned long long)(uintptr_t)s << 6) ^ (unsigned long long)dev; }
+}  // namespace
+
+extern "C" int dib_blur_step(const void *const *psf_ptrs, int psf_dtype, int num_psfs, int K, int normalize,
+                             const void *const *in_dev, void *const *out_dev, const int *C, const int *H, const int *W,
+                             const int *table_index, int B, int dtype, int acc_mode, void *tables_dev, int flags,
+                             void *stream) {
+  if (num_psfs <= 0 || !psf_ptrs) { set_error("dib_blur_step: no PSFs"); return DIB_EINVAL; }
+  if (K != 128 && K != 256) { set_error("dib_blur_step: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
+  if (psf_dtype != DIB_F16 && psf_dtype != DIB_F32) { set_error("dib_blur_step: unknown PSF dtype %d", psf_dtype); return DIB_EINVAL; }
+  if (flags & ~DIB_STEP_PSFS_COMPLETE) { set_error("dib_blur_step: unknown flags 0x%x", flags); return DIB_EINVAL; }
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  DIB_HIP_CHECK(hipStreamIsCapturing(s, &cap));
+  if (tables_dev || cap != hipStreamCaptureStatusNone) {
+    if (!tables_dev) {
+      set_error("dib_blur_step: the stream is being captured into a graph: pass a table buffer of dib_tap_tables_bytes(K, num_psfs) bytes");
+      return DIB_ECAPTURE;
+    }
+    // caller-owned tables: two ordinary launches in stream order
+    if (int rc = dib_psf_compact_list(psf_ptrs, psf_dtype, num_psfs, K, normalize, tables_dev, stream)) return rc;
+    return dib_sparse_blur(in_dev, out_dev, C, H, W, table_index, B, dtype, tables_dev, num_psfs, K, acc_mode, stream);
+  }
+  int dev = 0;
+  DIB_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_step_mutex);
+  StepState &st = g_step[key_of(dev, s)];
+  Slot &sl = st.slot[st.next & 1];
+  const size_t need = dib_tap_tables_bytes(K, num_psfs);
+  if (sl.bytes < need) {
+    if (sl.buf) {   // rare (a larger batch than any before on this stream): nobody may still read the old buffer
+      DIB_HIP_CHECK(hipStreamSynchronize(s));
+      DIB_HIP_CHECK(hipFree(sl.buf));
+      sl.buf = nullptr; sl.bytes = 0;
+    }
+    DIB_HIP_CHECK(hipMalloc((void **)&sl.buf, need));
+    sl.bytes = need;
+  }
+  if (int rc = compact_launch(psf_ptrs, psf_dtype, num_psfs, K, normalize, sl.buf, s, (flags & DIB_STEP_PSFS_COMPLETE) != 0)) return rc;
+  ++st.next;   // from here on the buffer counts as in use by this step, whatever the blur returns
+  return dib_sparse_blur(in_dev, out_dev, C, H, W, table_index, B, dtype, sl.buf, num_psfs, K, acc_mode, stream);
+}
+
+extern "C" int dib_blur_step_release(void) {
+  int dev = 0;
+  DIB_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_step_mutex);
+  DIB_HIP_CHECK(hipDeviceSynchronize());
+  for (auto it = g_step.begin(); it != g_step.end();) {
+    if ((int)(it->first & 63) != (dev & 63)) { ++it; continue; }
+    for (Slot &sl : it->second.slot)
+      if (sl.buf) DIB_HIP_CHECK(hipFree(sl.buf));
+    it = g_step.erase(it);
+  }
+  return DIB_OK;
+}

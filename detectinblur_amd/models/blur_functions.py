@@ -72,12 +72,18 @@ def manual_blur(image_GPU, psf_GPU, add_noise=False, noise_level=0.001, add_bloc
 
 
 def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_level=0.001, add_block=False,
-                    add_jpeg_artifact=False, jpeg_compressor=None, acc_mode=_lib.DIB_ACC_BITEXACT, tables=None):
+                    add_jpeg_artifact=False, jpeg_compressor=None, acc_mode=_lib.DIB_ACC_BITEXACT, tables=None,
+                    psfs_complete=False):
     """In place: images_GPU[i] is replaced by its blurred version when blur_dicts[i]["blurring"].
     PSFs arrive un-normalised and are divided by their sum here (reference :98).  Returns None.
     `tables` (beyond the reference's signature): tap tables of exactly the blurring PSFs, in order, compacted ahead
     of time with blur_ops.compact_psfs_ahead (normalize=True) -- the compaction then overlaps earlier GPU work, and
-    `utils.expand_targets(..., tables=)` can share them.  Without it the PSFs are compacted here, every call."""
+    `utils.expand_targets(..., tables=)` can share them.  Without it the PSFs are compacted here, every call, by the one
+    library call that also blurs (`blur_ops.blur_step`: compaction on the library's side stream).
+    `psfs_complete` (beyond the reference's signature as well): the caller states that the PSF tensors are complete when
+    this call is made -- e.g. resident PSFs, or the reference's own `torch.HalfTensor(psf).to(device)` (engine.py:84: a
+    synchronous copy) -- and not the product of kernels still queued on the current stream; the compaction then need not
+    wait for that stream and overlaps the previous batch's blur."""
     idx = [i for i, bd in enumerate(blur_dicts) if bd["blurring"]]
     if not idx:
         return None
@@ -97,9 +103,9 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_lev
             for dt in dts:
                 sub = [i for i in idx if psfs_GPU[i].shape[0] == K and psfs_GPU[i].dtype == dt]
                 if sub:
-                    _blur_group(images_GPU, psfs_GPU, sub, acc_mode, blur_dicts)
+                    _blur_group(images_GPU, psfs_GPU, sub, acc_mode, blur_dicts, psfs_complete=psfs_complete)
     else:
-        _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts)
+        _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts, psfs_complete=psfs_complete)
     if add_noise or add_block or add_jpeg_artifact:
         for i in idx:
             images_GPU[i] = _post_ops(images_GPU[i], add_noise, noise_level, add_block, add_jpeg_artifact,
@@ -107,17 +113,22 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_lev
     return None
 
 
-def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=None):
+def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=None, psfs_complete=False):
     K = psfs_GPU[idx[0]].shape[0]
     if K <= 129:
         for i in idx:
             sh = images_GPU[i].shape
             if sh[-2] == 64 or sh[-1] == 64:
                 _check_shapes(images_GPU[i], K)       # raises what the reference's reflect padding raises
+    psfs = None
     if tables is None:
-        psfs = [psfs_GPU[i] if psfs_GPU[i].dtype == images_GPU[i].dtype else psfs_GPU[i].to(images_GPU[i].dtype)
-                for i in idx]
-        tables = blur_ops.compact_psfs(psfs, normalize=True)
+        psfs = []
+        for i in idx:
+            p = psfs_GPU[i]
+            if p.dtype != images_GPU[i].dtype:
+                p = p.to(images_GPU[i].dtype)
+                psfs_complete = False           # the conversion was just queued on the current stream
+            psfs.append(p)
     # Scheduling hint (optional, host-side, never needed for correctness): `BlurImage` records the PSF's
     # tap count in blur_dict["psf_taps"].  Tiles are dispatched in descriptor order, so handing the
     # images over heaviest first lets the launch end on its cheapest tiles (~4 % at BASELINE shapes).
@@ -129,7 +140,10 @@ def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=Non
             taps = None
         if taps is not None:
             perm.sort(key=taps.__getitem__, reverse=True)      # stable: equal tap counts keep their order
-    outs = blur_ops.sparse_blur([images_GPU[idx[k]] for k in perm], perm, tables, acc_mode)
+    if tables is None:
+        outs = blur_ops.blur_step([images_GPU[idx[k]] for k in perm], perm, psfs, True, acc_mode, psfs_complete)
+    else:
+        outs = blur_ops.sparse_blur([images_GPU[idx[k]] for k in perm], perm, tables, acc_mode)
     for j, k in enumerate(perm):
         o = outs[j]
         images_GPU[idx[k]] = o.squeeze() if 1 in o.shape else o       # reference :69 squeezes every unit dim

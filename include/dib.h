@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 4 /* 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE); 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -32,6 +32,7 @@ extern "C" {
 #define DIB_ESHAPE (-2)  /* reference would raise: reflect padding needs H,W > 64 (or < 64)    */
 #define DIB_EHIP (-3)    /* a HIP runtime call failed; text in dib_last_error()                */
 #define DIB_ENOT128 (-4) /* expand_targets on a PSF that is not 128 wide (utils.py:369-370)    */
+#define DIB_ECAPTURE (-5) /* dib_blur_step on a stream under graph capture without caller tables */
 
 /* element types */
 #define DIB_F16 0
@@ -91,6 +92,32 @@ int dib_psf_compact_list(const void *const *psf_ptrs, int dtype, int B, int K, i
 int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, const int *C, const int *H,
                     const int *W, const int *table_index, int B, int dtype,
                     void *tables_dev, int num_tables, int K, int acc_mode, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One blur step = dib_psf_compact_list + dib_sparse_blur behind ONE call: `blur_image_list`
+ * (models/blur_functions.py:92-100) for a batch.  The first seven arguments are dib_psf_compact_list's (the batch's
+ * blurring PSFs, in table order), the next ten dib_sparse_blur's (table_index[i] indexes those PSFs).
+ *   tables_dev == NULL (the normal case): the tap tables live in two buffers per (device, stream) owned by the library
+ *     and used alternately -- the ONE exception to "no entry point allocates device memory": grown to the largest batch
+ *     seen on that stream, freed by dib_blur_step_release().  By default both launches are ordinary stream-ordered launches
+ *     (the PSFs may be the product of work queued on `stream` before the call, e.g. an asynchronous upload).
+ *     DIB_STEP_PSFS_COMPLETE in `flags` states that the PSF buffers are already complete when the call is made (resident
+ *     PSFs; the reference's own `torch.HalfTensor(psf).to(device)` of engine.py:84, a synchronous copy from pageable
+ *     memory): the compaction is then launched without a barrier in front of it (hipExtAnyOrderLaunch) and overlaps the
+ *     kernel queued before it on `stream` -- the previous step's blur; the blur of this step waits for it as for any earlier
+ *     launch.
+ *   tables_dev != NULL: dib_tap_tables_bytes(K, num_psfs) bytes owned by the caller; two ordinary launches.  Required
+ *     while `stream` is being captured into a HIP graph (a replay must not touch the library's buffers): without it the
+ *     call returns DIB_ECAPTURE and launches nothing.
+ * Results are those of the two separate calls, bit for bit.  No host synchronisation (except when a batch outgrows the
+ * stream's table buffers: that call waits for the stream once).
+ * ------------------------------------------------------------------------------------- */
+#define DIB_STEP_PSFS_COMPLETE 1
+int dib_blur_step(const void *const *psf_ptrs, int psf_dtype, int num_psfs, int K, int normalize,
+                  const void *const *in_dev, void *const *out_dev, const int *C, const int *H, const int *W,
+                  const int *table_index, int B, int dtype, int acc_mode, void *tables_dev, int flags,
+                  void *stream);
+int dib_blur_step_release(void);
 
 /* ---------------------------------------------------------------------------------------
  * Fused epilogue of the blur for the detector's input: `.float()` (engine.py:107-110), per-image
