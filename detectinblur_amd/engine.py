@@ -103,6 +103,13 @@ def _estimate(blur_estimator, x, graphed):
     if cache is None:
         from .graphs import GraphCache
         cache = core.__dict__["_dib_graphs"] = GraphCache(blur_estimator)
+    # the graphs read the estimator's parameters and statistics through their live pointers (in-place updates are seen);
+    # storage that was REPLACED since the capture (.to(), .half()) leaves them dangling: start over
+    ptrs = tuple(t.data_ptr() for t in core.parameters()) + tuple(t.data_ptr() for t in core.buffers())
+    if core.__dict__.get("_dib_graph_ptrs") != ptrs:
+        if "_dib_graph_ptrs" in core.__dict__:
+            cache.clear()
+        core.__dict__["_dib_graph_ptrs"] = ptrs
     return cache(x).clone()
 
 

@@ -11,7 +11,11 @@ import torch
 
 
 class StaticGraph(object):
-    def __init__(self, fn, example, warmup=2):
+    """The graph holds RAW POINTERS to everything its launches read.  What lives outside the capture's memory pool and is not
+    kept alive by anybody else (cached anchors, lookup tables) must therefore be among `fn`'s outputs: `self.out` is the
+    reference that keeps it alive as long as the graph (generalized_rcnn._trunk returns its anchors for that reason)."""
+
+    def __init__(self, fn, example, warmup=2, pool=None):
         self.static_in = example.clone(memory_format=torch.preserve_format)
         cur = torch.cuda.current_stream(example.device)
         side = torch.cuda.Stream(device=example.device)
@@ -23,7 +27,7 @@ class StaticGraph(object):
         torch.cuda.synchronize(example.device)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: a DataLoader's pin-memory thread allocating host memory must not invalidate the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
             self.out = fn(self.static_in)
 
     def __call__(self, x):
@@ -33,23 +37,39 @@ class StaticGraph(object):
 
 
 class GraphCache(object):
-    """shape-keyed StaticGraphs of one function; a shape whose capture failed runs eagerly from then on."""
+    """Shape-keyed StaticGraphs of one function, least recently used first out; a shape whose capture failed runs eagerly from
+    then on.  A shape is captured when it is seen for the `capture_after`-th time (rare shapes of a varied dataset stay eager
+    instead of evicting a common shape's graph: the reference evaluates COCO at batch 1, dozens of padded shapes).  All graphs
+    of one cache share ONE memory pool: they are replayed one at a time and their outputs are consumed in stream order before
+    the next replay, so the pool holds the largest shape's activations, not the sum over the shapes."""
 
-    def __init__(self, fn, limit=8):
-        self.fn, self.limit, self.graphs = fn, limit, {}
+    def __init__(self, fn, limit=16, capture_after=2):
+        self.fn, self.limit, self.capture_after = fn, limit, capture_after
+        self.graphs, self.seen, self.pool = {}, {}, None
+
+    def clear(self):
+        self.graphs.clear()
+        self.seen.clear()
 
     def __call__(self, x):
         key = (tuple(x.shape), x.dtype, x.device, x.is_contiguous(memory_format=torch.channels_last))
-        g = self.graphs.get(key)
-        if g is None and key not in self.graphs:
-            if len(self.graphs) >= self.limit:
-                self.graphs.pop(next(iter(self.graphs)))
-            try:
-                g = StaticGraph(self.fn, x)
-            except Exception as e:      # noqa: BLE001 -- e.g. an op that synchronises; stay correct, stay eager
-                import sys
-                sys.stderr.write("detectinblur_amd.graphs: capture failed for %s (%s: %s); running eagerly\n" % (key[0], type(e).__name__, e))
-                torch.cuda.synchronize()
-                g = None
-            self.graphs[key] = g
+        if key in self.graphs:
+            g = self.graphs.pop(key)
+            self.graphs[key] = g                    # most recently used last
+            return g(x) if g is not None else self.fn(x)
+        n = self.seen[key] = self.seen.get(key, 0) + 1
+        if n < self.capture_after:
+            return self.fn(x)
+        while len(self.graphs) >= self.limit:
+            self.graphs.pop(next(iter(self.graphs)))        # least recently used
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        try:
+            g = StaticGraph(self.fn, x, pool=self.pool)
+        except Exception as e:      # noqa: BLE001 -- e.g. an op that synchronises; stay correct, stay eager
+            import sys
+            sys.stderr.write("detectinblur_amd.graphs: capture failed for %s (%s: %s); running eagerly\n" % (key[0], type(e).__name__, e))
+            torch.cuda.synchronize()
+            g = None
+        self.graphs[key] = g
         return g(x) if g is not None else self.fn(x)

@@ -80,8 +80,11 @@ class _BiasAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        if ctx.masked and ctx.state is not None and ctx.state.get("consumer_masks"):
-            pass        # the one consumer of this output (_BlockEntry) applied the mask while it accumulated the gradient
+        handed = ctx.state.get("masked_grad") if (ctx.masked and ctx.state is not None) else None
+        if handed is not None and handed == (grad.data_ptr(), grad._version, tuple(grad.shape)):
+            # this gradient IS the tensor the output's _BlockEntry returned, untouched since (autograd's in-place accumulation
+            # of a second consumer's gradient would have bumped its version): the mask was applied while it was accumulated
+            pass
         elif ctx.masked:
             from .. import _lib
             (mask,) = ctx.saved_tensors
@@ -143,6 +146,18 @@ def _as_gemm(x, conv, forward_only=False):
     # counts are small -- 1024 -> 256 at M = 33,600: 0.193 -> 0.145 ms (b = 8); at b = 1 every 1x1 of the trunk but
     # 64 -> 64: 2.28 -> 1.60 ms per image (scratch/t_b1_shapes.py)
     return (forward_only or not torch.is_grad_enabled()) and M <= 67200 and max(conv.in_channels, conv.out_channels) >= 128
+
+
+# Inference only: the strided 1x1 "downsample" convolution of a stage's first block as a GEMM on the gathered pixels (what
+# _DownEntry does in training).  MIOpen's kernels for these shapes at small M accumulate with atomics: two runs on the same
+# input differ in the last bits (scratch/t_nondet.py, profiles/r4_nondeterminism.txt), which a replayed HIP graph must not.
+STRIDED_1X1_GEMM = True
+
+
+def _as_strided_gemm(x, conv):
+    return (STRIDED_1X1_GEMM and not torch.is_grad_enabled() and conv.kernel_size == (1, 1) and conv.stride[0] == conv.stride[1]
+            and conv.stride[0] > 1 and conv.padding == (0, 0) and conv.groups == 1 and x.is_cuda and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last) and max(conv.in_channels, conv.out_channels) >= 128)
 
 
 # MIOpen's channels-last fp32 kernels are the fast ones for the large activations of this network; for the small-M, wide 3x3
@@ -212,6 +227,10 @@ def conv1x1(x, weight, bias, conv):
         if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
             return _Gemm1x1.apply(x, weight, bias)
         return F.linear(x.permute(0, 2, 3, 1), weight.reshape(conv.out_channels, conv.in_channels), bias).permute(0, 3, 1, 2)
+    if _as_strided_gemm(x, conv):
+        s = conv.stride[0]
+        xs = x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last)
+        return F.linear(xs.permute(0, 2, 3, 1), weight.reshape(conv.out_channels, conv.in_channels), bias).permute(0, 3, 1, 2)
     if _as_planar(x, conv):
         y = F.conv2d(x.contiguous(), weight.contiguous(), bias, conv.stride, conv.padding, conv.dilation, conv.groups)
         return y.contiguous(memory_format=torch.channels_last)
@@ -233,8 +252,9 @@ def _conv1x1_base(x, weight, conv):
 # The input of an identity-skip bottleneck feeds its first convolution AND its skip connection: autograd would add the two
 # gradients (a 12 B / element pass) and the ReLU behind that input would mask the sum in another pass (8.25 B).  _BlockEntry is
 # that first 1x1 convolution plus the skip as ONE autograd node: its backward accumulates and masks in place on the fresh data
-# gradient (dib_add_relu_mask, 12.25 B), and tells the producing _BiasAct -- whose only consumer it is inside a ResNet stage --
-# that its mask has been applied.  Values identical to the unfused graph (the mask is idempotent and linear).
+# gradient (dib_add_relu_mask, 12.25 B), and tells the producing _BiasAct WHICH gradient tensor (pointer + version) carries the
+# mask already; the producer skips its own mask pass only for exactly that tensor, so a second consumer of the output (a hook,
+# an auxiliary loss) costs a pass, never a wrong gradient.  Values identical to the unfused graph (the mask is idempotent and linear).
 BLOCK_ENTRY = True
 
 
@@ -242,11 +262,8 @@ class _BlockEntry(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, state, conv):
         ctx.conv = conv
-        mask = None
-        if state is not None and state.get("mask") is not None:
-            state["consumer_masks"] = True
-            mask = state["mask"]
-        ctx.has_mask = mask is not None
+        mask = state.get("mask") if state is not None else None
+        ctx.has_mask, ctx.state = mask is not None, (state if mask is not None else None)
         ctx.save_for_backward(x, weight, *([mask] if mask is not None else []))
         return _conv1x1_base(x, weight, conv), x.view_as(x)
 
@@ -271,6 +288,10 @@ class _BlockEntry(torch.autograd.Function):
             elif mask is not None:
                 _lib.check(_lib.lib().dib_relu_mask_backward(dx.data_ptr(), mask.data_ptr(), dx.data_ptr(), dx.numel(),
                                                              torch.cuda.current_stream().cuda_stream))
+            if mask is not None:
+                # tell the producing _BiasAct which gradient tensor already carries its ReLU mask; it re-applies the mask (idempotent
+                # and linear, so always correct) to anything else -- e.g. the sum autograd forms when the output has a second consumer
+                ctx.state["masked_grad"] = (dx.data_ptr(), dx._version, tuple(dx.shape))
         return (dx if need_x else None), (dw if need_w else None), None, None
 
 
@@ -341,19 +362,60 @@ def block_entry(x, conv, bn):
     return bias_act(out, shift, None, True), skip
 
 
+def _fold_key(conv, bn):
+    return (conv.weight.data_ptr(), conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
+            bn.running_var._version, bn.weight.data_ptr())
+
+
 def _folded(conv, bn):
-    """(weight * scale, shift) of a convolution + frozen batch-norm pair, cached while neither changes: in inference the
-    fold is 5 tiny launches per convolution (~1 ms of GPU time per image at batch 1) for values that never move."""
-    key = (conv.weight.data_ptr(), conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
-           bn.running_var._version, bn.weight.data_ptr())
+    """(weight * scale, shift) of a convolution + frozen batch-norm pair for inference, cached while neither changes (the fold
+    is 5 tiny launches per convolution, ~1 ms of GPU time per image at batch 1, for values that never move).  The two result
+    tensors are allocated ONCE per pair and from then on REWRITTEN IN PLACE when a weight or statistic changed: a HIP graph
+    captured over them (graphs.py) keeps valid pointers and reads current values once `refresh_folded` has run."""
+    key = _fold_key(conv, bn)
     hit = conv.__dict__.get("_dib_fold")
     if hit is None or hit[0] != key:
         with torch.no_grad():
             scale, shift = bn.affine()
-            hit = (key, (conv.weight * scale.reshape(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
-                   if conv.weight.is_contiguous(memory_format=torch.channels_last) else conv.weight * scale.reshape(-1, 1, 1, 1), shift.contiguous())
+            w = conv.weight * scale.reshape(-1, 1, 1, 1)
+            if conv.weight.is_contiguous(memory_format=torch.channels_last):
+                w = w.contiguous(memory_format=torch.channels_last)
+            if (hit is not None and hit[1].shape == w.shape and hit[1].stride() == w.stride() and hit[1].device == w.device
+                    and hit[1].dtype == w.dtype):
+                hit[1].copy_(w)
+                hit[2].copy_(shift)
+                hit = (key, hit[1], hit[2])
+            else:
+                hit = (key, w, shift.contiguous())
         conv.__dict__["_dib_fold"] = hit
     return hit[1], hit[2]
+
+
+def refresh_folded(module):
+    """Bring every cached fold under `module` up to date, in place (see _folded).  Returns the number of folds rewritten.
+    Cheap when nothing changed: seven attribute reads per convolution."""
+    n = 0
+    for conv, bn in _fold_pairs(module):
+        hit = conv.__dict__.get("_dib_fold")
+        if hit is not None and hit[0] != _fold_key(conv, bn):
+            _folded(conv, bn)
+            n += 1
+    return n
+
+
+def _fold_pairs(module):
+    pairs = module.__dict__.get("_dib_fold_pairs")
+    if pairs is None:
+        pairs = []
+        for m in module.modules():
+            if isinstance(m, Bottleneck):
+                pairs += [(m.conv1, m.bn1), (m.conv2, m.bn2), (m.conv3, m.bn3)]
+                if m.downsample is not None:
+                    pairs.append((m.downsample[0], m.downsample[1]))
+            elif isinstance(m, ResNet50Body):
+                pairs.append((m.conv1, m.bn1))
+        module.__dict__["_dib_fold_pairs"] = pairs
+    return pairs
 
 
 class _WideOut1x1(torch.autograd.Function):

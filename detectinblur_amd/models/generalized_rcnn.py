@@ -30,7 +30,29 @@ class GeneralizedRCNN(nn.Module):
         fl = list(feats.values())
         from .net_transforms import ImageList
         anchors = self.rpn.anchor_generator(ImageList(x, [None] * x.shape[0]), fl)[0]
-        return tuple(fl) + tuple(self.rpn.propose_static(fl, anchors, self._sizes[x.shape[0]]))
+        # `anchors` comes out of the generator's one-entry cache and is read by a captured graph through its raw pointer: it
+        # travels with the outputs so that the StaticGraph keeps it alive after the cache has moved on to another geometry
+        return tuple(fl) + tuple(self.rpn.propose_static(fl, anchors, self._sizes[x.shape[0]])) + (anchors,)
+
+    def _sync_graphs_with_weights(self, cache):
+        """A captured trunk reads the FPN / RPN parameters through their live pointers and the trunk's convolutions through the
+        cached batch-norm folds (backbone._folded).  Before every replay: (1) if any parameter or buffer of the trunk was
+        REPLACED (another storage: .to(), .half(), a re-assigned .data) the graphs hold dangling pointers -- drop them; (2) folds
+        whose convolution or statistics changed IN PLACE since (an optimizer step between two evaluations, load_state_dict)
+        are rewritten in place, so the graphs read current values.  ~300 attribute reads per call, nothing on the device
+        unless something changed."""
+        from .backbone import refresh_folded
+        tensors = self.__dict__.get("_trunk_tensors")
+        if tensors is None:
+            tensors = self.__dict__["_trunk_tensors"] = ([p for p in self.backbone.parameters()] + [b for b in self.backbone.buffers()]
+                                                         + [p for p in self.rpn.parameters()])
+        ptrs = tuple(t.data_ptr() for t in tensors)
+        if self.__dict__.get("_trunk_ptrs") != ptrs:
+            if "_trunk_ptrs" in self.__dict__:
+                cache.clear()
+                self.__dict__.pop("_trunk_tensors")         # parameters may have been re-registered
+            self.__dict__["_trunk_ptrs"] = ptrs
+        refresh_folded(self.backbone)
 
     def _forward_graphed(self, images, original_sizes):
         from ..graphs import GraphCache
@@ -44,9 +66,10 @@ class GeneralizedRCNN(nn.Module):
         cache = self.__dict__.get("_trunk_graphs")
         if cache is None:
             cache = self.__dict__["_trunk_graphs"] = GraphCache(self._trunk)
+        self._sync_graphs_with_weights(cache)
         outs = cache(x)
-        features = OrderedDict(zip(self._feat_names, outs[:-3]))
-        proposals, _ = self.rpn.unpad(*outs[-3:])
+        features = OrderedDict(zip(self._feat_names, outs[:-4]))
+        proposals, _ = self.rpn.unpad(*outs[-4:-1])
         detections, _ = self.roi_heads(features, proposals, images.image_sizes, None)
         return self.transform.postprocess(detections, images.image_sizes, original_sizes)
 

@@ -84,7 +84,13 @@ class RPNHead(nn.Module):
                 deltas.append(self.bbox_pred(t))
                 continue
             t = bias_act(conv1x1(f, self.conv.weight, None, self.conv), self.conv.bias, relu=True)   # shape-based kernel choice
-            both = F.conv2d(t, w, b)
+            if torch.is_grad_enabled():
+                both = F.conv2d(t, w, b)
+            else:
+                # inference: the same contraction as a GEMM on the NHWC view.  MIOpen's kernel for this 1 x 1 convolution with 16
+                # output channels accumulates with atomics at every level but the largest: two runs on the same input differ in
+                # the last bits, and with them the proposals (scratch/t_pred_conv.py: 20 of 20 runs differ; the GEMM: 0, same time)
+                both = F.linear(t.permute(0, 2, 3, 1), w.view(w.shape[0], -1), b).permute(0, 3, 1, 2)
             logits.append(both[:, :A])
             deltas.append(both[:, A:5 * A])
         return logits, deltas

@@ -1,0 +1,74 @@
+"""Which kernel of the inference trunk is not bit-reproducible?  (a) replay one captured trunk graph twice on the same input and
+compare every output; (b) wrap conv2d / linear / mm / topk / sort / nms / roi_align so that each call runs TWICE on the same
+input and report the ones whose two results differ."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.nn.functional as F
+from detectinblur_amd.models.faster_rcnn import fasterrcnn_resnet50_fpn
+from detectinblur_amd.models import backbone as BB, detector_ops as ops, rpn as RPN
+
+torch.manual_seed(0)
+if os.environ.get("DET") == "1":
+    torch.backends.cudnn.deterministic = True
+kw = dict(min_size=int(sys.argv[1]), max_size=int(sys.argv[2])) if len(sys.argv) > 2 else {}
+m = fasterrcnn_resnet50_fpn(num_classes=91, pretrained=False, pretrained_backbone=False, **kw).cuda().eval()
+H, W = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (800, 1333)
+img = torch.rand(3, H, W, device="cuda")
+means, stds = np.tile([0.485, 0.456, 0.406], (1, 1)), np.tile([0.229, 0.224, 0.225], (1, 1))
+
+with torch.no_grad():
+    m.graph_inference = True
+    d0 = m([img], newMeans=means, newSTDs=stds)
+    g = list(m._trunk_graphs.graphs.values())[0]
+    x = g.static_in.clone()
+    a = [t.clone() for t in g(x)]
+    for trial in range(5):
+        b = [t.clone() for t in g(x)]
+        diffs = [float((p.float() - q.float()).abs().max()) for p, q in zip(a, b)]
+        print("graph replay %d vs 0: max abs diff per output" % (trial + 1), ["%.3g" % d for d in diffs], [tuple(t.shape) for t in a] if trial == 0 else "")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        g(x)
+    e1.record(); e1.synchronize()
+    print("trunk graph replay: %.3f ms" % (e0.elapsed_time(e1) / 50))
+    m.graph_inference = False
+
+    # (b) every op twice
+    report = {}
+
+    def twice(name, fn):
+        def w(*args, **kwargs):
+            r1 = fn(*args, **kwargs)
+            r2 = fn(*args, **kwargs)
+            l1 = r1 if isinstance(r1, (tuple, list)) else (r1,)
+            l2 = r2 if isinstance(r2, (tuple, list)) else (r2,)
+            for p, q in zip(l1, l2):
+                if torch.is_tensor(p) and not torch.equal(p, q):
+                    shp = [tuple(t.shape) for t in args if torch.is_tensor(t)]
+                    key = (name, str(shp))
+                    d = float((p.float() - q.float()).abs().max())
+                    report[key] = max(report.get(key, 0.0), d)
+            return r1
+        return w
+
+    F.conv2d = twice("conv2d", F.conv2d)
+    F.linear = twice("linear", F.linear)
+    torch.mm = twice("mm", torch.mm)
+    torch.addmm = twice("addmm", torch.addmm)
+    ops.nms_sets_sorted = twice("nms_sets_sorted", ops.nms_sets_sorted)
+    for nm in ("roi_align", "multiscale_roi_align", "batched_nms", "nms"):
+        if hasattr(ops, nm):
+            setattr(ops, nm, twice(nm, getattr(ops, nm)))
+    _topk = torch.Tensor.topk
+    torch.Tensor.topk = twice("topk", _topk)
+    for trial in range(3):
+        m([img], newMeans=means, newSTDs=stds)
+    print("ops whose two runs on the same input differ:")
+    for k, v in sorted(report.items()):
+        print("   ", k, "max abs diff %.3g" % v)
+    if not report:
+        print("    none")

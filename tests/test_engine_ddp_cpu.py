@@ -70,43 +70,82 @@ def test_train_one_epoch_and_evaluate_cpu(tmp_path):
 
 
 _DDP_SCRIPT = r'''
-import os, sys, torch, torch.distributed as dist
+import copy, os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 from detectinblur_amd import utils
-from tests.test_engine_ddp_cpu import _small_model
+from tests.test_engine_ddp_cpu import _small_model, _rank_batch
 class A: pass
 args = A(); args.dist_url = "env://"
 utils.init_distributed_mode(args)
 assert args.distributed and args.dist_backend == "gloo" and dist.get_world_size() == 2
-m = _small_model()
-ddp = torch.nn.parallel.DistributedDataParallel(m)
 rank = dist.get_rank()
-g = torch.Generator().manual_seed(100 + rank)
-imgs = [torch.rand(3, 90, 120, generator=g)]
-tg = [{"boxes": torch.tensor([[10. + rank, 20., 60., 70.]]), "labels": torch.tensor([3 + rank])}]
-ddp.train()
-torch.manual_seed(5)             # same sampling decisions on both ranks
-losses = ddp(imgs, tg)
-red = utils.reduce_dict(losses)
-sum(losses.values()).backward()
-# after DDP's all-reduce every rank holds the same (averaged) gradient
-gsum = torch.cat([p.grad.flatten()[:50] for p in m.parameters() if p.grad is not None][:5])
-out = [torch.zeros_like(gsum) for _ in range(2)]
-dist.all_gather(out, gsum)
-assert torch.allclose(out[0], out[1]), "gradients differ across ranks"
+m = _small_model()
+bare = copy.deepcopy(m)                       # the same weights, never wrapped
+ddp = torch.nn.parallel.DistributedDataParallel(m, broadcast_buffers=False, gradient_as_bucket_view=True)   # reference train.py:238-241 + bench.py
+opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.01, momentum=0.9)
+opt_bare = torch.optim.SGD([p for p in bare.parameters() if p.requires_grad], lr=0.01, momentum=0.9)
+ddp.train(); bare.train()
+for step in range(2):
+    # --- the DDP step on this rank's shard
+    imgs, tg = _rank_batch(rank, step)
+    torch.manual_seed(5 + step)                # the detector's samplers draw from the global generator: same draws in the reference run below
+    losses = ddp(imgs, tg)
+    red = utils.reduce_dict(losses)
+    opt.zero_grad()
+    sum(losses.values()).backward()
+    # --- what it must equal: the MEAN over the ranks of the per-rank gradients, computed in THIS process without DDP
+    want = None
+    for r in range(2):
+        ri, rt = _rank_batch(r, step)
+        torch.manual_seed(5 + step)
+        opt_bare.zero_grad()
+        sum(bare(ri, rt).values()).backward()
+        g = [p.grad.detach().clone() for p in bare.parameters() if p.requires_grad]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    want = [w / 2 for w in want]
+    got = [p.grad for p in m.parameters() if p.requires_grad]
+    assert len(got) == len(want) > 80
+    worst = 0.0
+    for (name, _), a, b in zip([(n, p) for n, p in m.named_parameters() if p.requires_grad], got, want):
+        err = float((a - b).norm()) / (float(b.norm()) + 1e-12)
+        worst = max(worst, err)
+        # step 0: identical weights on both sides.  step 1: the two copies' weights agree to rounding only (the all-reduce sums in
+        # another order than `want`), and a pre-activation that is ~0 may fall on the other side of its ReLU: 1e-3 -- a missing
+        # bucket, a sum instead of the mean or a stale gradient is off by tens of per cent
+        assert err <= (1e-5 if step == 0 else 1e-3), (step, name, err)
+    # the per-rank gradients really differ (else the mean proves nothing): rank r's own gradient is not the mean
+    own = [p.grad.detach().clone() for p in bare.parameters() if p.requires_grad]      # left from r = 1
+    assert max(float((a - b).norm()) / (float(b.norm()) + 1e-12) for a, b in zip(own, want)) > 1e-2
+    # both copies take the same step: the bare model with the reference mean, the wrapped one with DDP's gradient
+    for p, w in zip([p for p in bare.parameters() if p.requires_grad], want):
+        p.grad = w
+    opt.step(); opt_bare.step()
+    for (name, a), b in zip(m.named_parameters(), bare.parameters()):
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-9, (step, name)
 got = utils.all_gather({"rank": rank})
 assert [d["rank"] for d in got] == [0, 1]
 vals = [torch.zeros(1) for _ in range(2)]
 dist.all_gather(vals, red["loss_classifier"].detach().reshape(1))
 assert torch.allclose(vals[0], vals[1])
-import sys
-sys.stdout.write("rank %%d ok\n" %% rank)    # one write per rank: the two ranks share the pipe
+sys.stdout.write("rank %%d ok worst %%.2e\n" %% (rank, worst))    # one write per rank: the two ranks share the pipe
 sys.stdout.flush()
 dist.destroy_process_group()
 '''
 
 
+def _rank_batch(rank, step):
+    """rank `rank`'s shard of step `step`: one image and one target, different on every rank and step"""
+    g = torch.Generator().manual_seed(100 + 10 * step + rank)
+    imgs = [torch.rand(3, 90, 120, generator=g)]
+    tg = [{"boxes": torch.tensor([[10. + 7 * rank, 20. + 3 * step, 60. + 5 * rank, 70.]]), "labels": torch.tensor([3 + rank])}]
+    return imgs, tg
+
+
 def test_ddp_gloo_world_size_2(tmp_path):
+    """Two ranks over gloo, two consecutive steps: the gradient DDP (bucket views, no buffer broadcast: the wrapper of
+    reference train.py:238-241 as bench.py builds it) leaves on every rank EQUALS the mean of the two per-rank gradients
+    computed in one process without DDP (same weights, same sampler draws), to 1e-5 of each tensor's norm (1e-3 in the second step); the per-rank
+    gradients differ from that mean by > 1e-2; the weights after the optimizer step agree."""
     script = tmp_path / "ddp_worker.py"
     script.write_text(_DDP_SCRIPT % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")

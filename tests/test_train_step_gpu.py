@@ -134,40 +134,136 @@ def test_degenerate_boxes_raise_on_the_gpu_without_draining_the_queue():
     assert all(torch.isfinite(v) for v in losses.values())
 
 
-def test_graphed_inference_equals_eager_inference():
+def _full_model():
+    from detectinblur_amd.models.faster_rcnn import fasterrcnn_resnet50_fpn
+    torch.manual_seed(0)
+    return fasterrcnn_resnet50_fpn(pretrained=False, pretrained_backbone=False, num_classes=91).cuda().eval()
+
+
+_MEANS = lambda n: np.tile([0.485, 0.456, 0.406], (n, 1))          # noqa: E731
+_STDS = lambda n: np.tile([0.229, 0.224, 0.225], (n, 1))           # noqa: E731
+
+
+def _det_equal(a, b):
+    return all(torch.equal(x[k], y[k]) for x, y in zip(a, b) for k in ("boxes", "labels", "scores"))
+
+
+def test_graphed_inference_is_bit_reproducible_and_equals_eager_inference():
     """engine.evaluate runs the detector's static trunk (backbone + FPN + RPN head + proposal filtering) as a HIP graph per
-    input shape: the recorded launches of the eager code.  The trunk's outputs (pyramid features, the best proposals) equal the
-    eager ones to the ~1e-6 by which two eager passes differ (MIOpen's kernel choice varies between calls); the detections
-    of a random-init head sit on score / NMS thresholds, so their count may differ by a few and the best ones must agree --
-    for two shapes, repeated replays and changing image sizes inside one padded shape."""
-    m = _model().eval()
+    input shape: the recorded launches of the eager code.  At the evaluation sizes (min 800 / max 1333, batch 1: what the
+    reference evaluates, evaluate.py:335-339) every kernel of the inference path is deterministic -- the two that were not,
+    MIOpen's atomically accumulating kernels for the 16-channel RPN predictor and the strided downsample convolutions, are
+    GEMMs in inference (profiles/r4_nondeterminism.txt) -- so: two replays on the same input are EQUAL, a replay equals the
+    eager trunk, and graphed detections equal eager detections in full (boxes, labels, scores), for a shape that needs no
+    resize, one that does (600 x 800 -> 800 x 1066, padded to 1088), a portrait one, repeated and interleaved."""
+    m = _full_model()
     torch.manual_seed(1)
-    batches = [[torch.rand(3, 150, 210, device="cuda")], [torch.rand(3, 150, 210, device="cuda")], [torch.rand(3, 140, 200, device="cuda")],
-               [torch.rand(3, 120, 224, device="cuda"), torch.rand(3, 150, 190, device="cuda")], [torch.rand(3, 150, 210, device="cuda")]]
-    means = lambda n: np.tile([0.485, 0.456, 0.406], (n, 1))          # noqa: E731
-    stds = lambda n: np.tile([0.229, 0.224, 0.225], (n, 1))           # noqa: E731
+    images = [torch.rand(3, 800, 1333, device="cuda"), torch.rand(3, 600, 800, device="cuda"), torch.rand(3, 640, 480, device="cuda")]
+    order = [0, 1, 0, 2, 1, 0, 2]
     with torch.no_grad():
-        eager = [m(list(b), newMeans=means(len(b)), newSTDs=stds(len(b))) for b in batches]
+        eager = [m([images[i]], newMeans=_MEANS(1), newSTDs=_STDS(1)) for i in order]
+        eager2 = [m([images[i]], newMeans=_MEANS(1), newSTDs=_STDS(1)) for i in order]
+        assert all(_det_equal(a, b) for a, b in zip(eager, eager2))                  # the eager path itself is reproducible
         m.graph_inference = True
-        graphed = [m(list(b), newMeans=means(len(b)), newSTDs=stds(len(b))) for b in batches]
-        again = [m(list(b), newMeans=means(len(b)), newSTDs=stds(len(b))) for b in batches]
-        assert len(m._trunk_graphs.graphs) == 2 and all(g is not None for g in m._trunk_graphs.graphs.values())     # captured, not eager
-        # the trunk itself: graph replay vs the eager function on the same padded batch
-        for b in (batches[0], batches[3]):
-            imgs, _ = m.transform(list(b), None, means(len(b)), stds(len(b)))
-            m._sizes[len(b)].copy_(torch.tensor([[float(s[1]), float(s[0])] for s in imgs.image_sizes], device="cuda"))
+        graphed = [m([images[i]], newMeans=_MEANS(1), newSTDs=_STDS(1)) for i in order]
+        again = [m([images[i]], newMeans=_MEANS(1), newSTDs=_STDS(1)) for i in order]
+        cache = m._trunk_graphs
+        assert len(cache.graphs) == 3 and all(g is not None for g in cache.graphs.values())     # captured (2nd sighting), not eager
+        assert len(eager[0][0]["boxes"]) > 0
+        for e, g, a in zip(eager, graphed, again):
+            assert _det_equal(e, g) and _det_equal(e, a)
+        # the trunk itself: replay vs replay, replay vs the eager function, on the same padded batch
+        for i in (0, 1):
+            imgs, _ = m.transform([images[i]], None, _MEANS(1), _STDS(1))
+            m._sizes[1].copy_(torch.tensor([[float(s[1]), float(s[0])] for s in imgs.image_sizes], device="cuda"))
             want = [t.clone() for t in m._trunk(imgs.tensors)]
-            got = m._trunk_graphs(imgs.tensors)
-            for w, g in zip(want[:-3], got[:-3]):                                   # pyramid features
-                assert torch.allclose(g, w, rtol=0, atol=1e-4 * float(w.abs().max()))
-            nw, ng = want[-1].tolist(), got[-1].tolist()                            # proposals kept after NMS, best first
-            for i in range(len(b)):
-                assert abs(nw[i] - ng[i]) <= 5 and ng[i] > 10
-                assert torch.allclose(got[-3][i, :10], want[-3][i, :10], atol=1e-2) and torch.allclose(got[-2][i, :10], want[-2][i, :10], atol=1e-4)
-    for e, g, a in zip(eager, graphed, again):
-        for de, dg, da in zip(e, g, a):
-            for other in (de, da):
-                assert abs(len(dg["boxes"]) - len(other["boxes"])) <= 5
-                k = min(3, len(dg["boxes"]), len(other["boxes"]))
-                assert torch.allclose(dg["scores"][:k], other["scores"][:k], atol=1e-4)
-    assert len(eager[0][0]["boxes"]) > 0
+            one = [t.clone() for t in cache(imgs.tensors)]
+            two = [t.clone() for t in cache(imgs.tensors)]
+            assert int(one[-2][0]) > 100                                               # proposals kept
+            for w, a, b in zip(want, one, two):
+                assert torch.equal(a, b)
+                assert torch.equal(a, w)
+
+
+def test_graphed_inference_follows_weight_updates():
+    """A captured trunk reads the batch-norm folds through cached tensors (backbone._folded) and everything else through the
+    live parameters.  After an optimizer step on EVERY parameter, after load_state_dict, and after the parameters moved to
+    new storage, graphed inference equals eager inference with the current weights (the round-3 code replayed the folds of
+    the first evaluation: train.py evaluates after every epoch)."""
+    m = _model().eval()
+    m.roi_heads.score_thresh = 0.0              # a perturbed random-init head keeps detections to compare
+    torch.manual_seed(2)
+    img = [torch.rand(3, 150, 210, device="cuda")]
+    means, stds = _MEANS(1), _STDS(1)
+
+    def both():
+        with torch.no_grad():
+            m.graph_inference = False
+            e = m(list(img), newMeans=means, newSTDs=stds)
+            m.graph_inference = True
+            g = m(list(img), newMeans=means, newSTDs=stds)
+            g = [{k: v.clone() for k, v in d.items()} for d in g]
+        return e, g
+
+    def close(e, g):
+        # toy sizes: MIOpen's small-M kernels accumulate atomically (profiles/r4_nondeterminism.txt), so scores agree to ~1e-3 and
+        # the detection count to a few; stale weights move scores by far more than that (checked below: > 1e-2)
+        assert abs(len(e[0]["scores"]) - len(g[0]["scores"])) <= 5 and len(g[0]["scores"]) > 0
+        k = min(5, len(e[0]["scores"]), len(g[0]["scores"]))
+        assert torch.allclose(e[0]["scores"][:k], g[0]["scores"][:k], atol=2e-3), (e[0]["scores"][:k], g[0]["scores"][:k])
+
+    both(); e0, g0 = both()                      # second sighting: captured
+    assert len(m._trunk_graphs.graphs) == 1 and all(g is not None for g in m._trunk_graphs.graphs.values())
+    close(e0, g0)
+    graph = next(iter(m._trunk_graphs.graphs.values()))
+    # (1) an optimizer step on every parameter (conv weights of the frozen-BN trunk included); the gradients are synthetic
+    # (5 % of each tensor's mean magnitude): a real step on a random-init detector at this rate ends in NaNs
+    opt = torch.optim.SGD(m.parameters(), lr=1.0)
+    for p in m.parameters():
+        p.grad = torch.randn_like(p) * 0.05 * p.detach().abs().mean().clamp(min=1e-3)
+    opt.step()
+    m.eval()
+    e1, g1 = both()
+    assert next(iter(m._trunk_graphs.graphs.values())) is graph          # same graph, refreshed folds
+    close(e1, g1)
+    assert not torch.allclose(e1[0]["scores"][:3], e0[0]["scores"][:3], atol=1e-2)      # the step did move the detector
+    # (2) load_state_dict (in-place copies): back to a perturbed copy of the weights
+    sd = {k: (v * 1.05 if v.is_floating_point() and "running_var" not in k else v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    e2, g2 = both()
+    assert next(iter(m._trunk_graphs.graphs.values())) is graph
+    close(e2, g2)
+    # (3) parameters on new storage: the old graphs hold dangling pointers and are dropped
+    for p in m.backbone.parameters():
+        p.data = p.data.clone()
+    e3, g3 = both()
+    assert graph not in list(m._trunk_graphs.graphs.values())
+    both(); e4, g4 = both()
+    assert len(m._trunk_graphs.graphs) == 1
+    close(e4, g4)
+
+
+def test_graph_cache_survives_more_shapes_than_it_holds():
+    """Seven padded shapes through a cache of three graphs, revisited in an order that evicts and recaptures: every replay
+    still equals the eager trunk -- in particular the anchors each graph reads (the generator keeps ONE geometry cached; the
+    graph keeps its own alive) and the shared memory pool."""
+    from detectinblur_amd.graphs import GraphCache
+    m = _model().eval()
+    m.__dict__["_trunk_graphs"] = GraphCache(m._trunk, limit=3, capture_after=1)
+    m.roi_heads.score_thresh = 0.0
+    torch.manual_seed(3)
+    shapes = [(150, 210), (120, 224), (160, 160), (100, 224), (130, 200), (160, 224), (224, 140)]
+    imgs = [torch.rand(3, h, w, device="cuda") for h, w in shapes]
+    visit = [0, 1, 2, 3, 0, 4, 5, 1, 6, 0, 2, 3, 6, 5]
+    with torch.no_grad():
+        for i in visit:
+            m.graph_inference = True
+            g = m([imgs[i]], newMeans=_MEANS(1), newSTDs=_STDS(1))
+            g = [{k: v.clone() for k, v in d.items()} for d in g]
+            m.graph_inference = False
+            e = m([imgs[i]], newMeans=_MEANS(1), newSTDs=_STDS(1))
+            assert abs(len(e[0]["scores"]) - len(g[0]["scores"])) <= 5 and len(g[0]["scores"]) > 0, i
+            k = min(5, len(e[0]["scores"]), len(g[0]["scores"]))
+            assert torch.allclose(e[0]["scores"][:k], g[0]["scores"][:k], atol=2e-4), i
+            assert torch.allclose(e[0]["boxes"][:k], g[0]["boxes"][:k], atol=0.5), i
+    assert len(m._trunk_graphs.graphs) == 3
