@@ -44,6 +44,9 @@ _SIGNATURES = {
     "dib_normalize_pad": (ctypes.c_int, [_c_void_pp, ctypes.c_int, _c_int_p, _c_int_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p]),
+    "dib_normalize_resize_pad": (ctypes.c_int, [_c_void_pp, ctypes.c_int, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "dib_expand_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p]),
     "dib_clamp_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

@@ -371,11 +371,13 @@ def rasterize_psfs(traj, fractions, canvas=256, center=True, out_n=None, want64=
     return p64, p16
 
 
-def normalize_pad(images, means, stds, Hp, Wp, channels_last=False):
+def normalize_pad(images, means, stds, Hp, Wp, channels_last=False, out_sizes=None):
     """images: list of 3 x H x W CUDA tensors (float16 or float32, one dtype); means / stds: [B,3] rows (anything
     numpy can read; rounded to float32 like torch.as_tensor(row, dtype=float32)).  Returns the fp32 batch
     [B,3,Hp,Wp] (memory format channels_last on request) holding (x - mean) / std inside each image and 0 in the
-    padding: engine.py:107-110 + net_transforms.py:112-121 + :238-247 in one launch."""
+    padding: engine.py:107-110 + net_transforms.py:112-121 + :238-247 in one launch.  `out_sizes` ([(Ho, Wo)] per image): each
+    image is also resized to that size on the way (bilinear, align_corners=False, scale recomputed from the sizes:
+    net_transforms.py:151-175 as ATen computes it on the GPU); an image whose size is already (Ho, Wo) is not interpolated."""
     import ctypes
     import numpy as np
     B = len(images)
@@ -394,6 +396,12 @@ def normalize_pad(images, means, stds, Hp, Wp, channels_last=False):
     fmt = torch.channels_last if channels_last else torch.contiguous_format
     out = torch.empty((B, 3, Hp, Wp), dtype=torch.float32, device=first.device, memory_format=fmt)
     fp = ctypes.POINTER(ctypes.c_float)
+    if out_sizes is not None and any((int(oh), int(ow)) != (h, w) for (oh, ow), h, w in zip(out_sizes, Hs, Ws)):
+        _lib.check(_lib.lib().dib_normalize_resize_pad(_lib.ptr_array(ptrs), _DT[first.dtype], _lib.int_array(Hs), _lib.int_array(Ws),
+                                                       _lib.int_array([int(o[0]) for o in out_sizes]), _lib.int_array([int(o[1]) for o in out_sizes]),
+                                                       B, m.ctypes.data_as(fp), sd.ctypes.data_as(fp), out.data_ptr(), Hp, Wp,
+                                                       int(bool(channels_last)), _stream(first.device)))
+        return out
     _lib.check(_lib.lib().dib_normalize_pad(_lib.ptr_array(ptrs), _DT[first.dtype], _lib.int_array(Hs), _lib.int_array(Ws), B,
                                             m.ctypes.data_as(fp), sd.ctypes.data_as(fp), out.data_ptr(), Hp, Wp,
                                             int(bool(channels_last)), _stream(first.device)))

@@ -114,8 +114,9 @@ class GeneralizedRCNNTransform(nn.Module):
         return scale
 
     def _forward_fused(self, images, targets, newMeans, newSTDs):
-        """None when the batch does not qualify (not on the GPU, mixed dtypes, crop mode, any image that needs a
-        resize); generator draws are consumed either way, exactly as the unfused path would."""
+        """None when the batch does not qualify (not on the GPU, mixed dtypes, crop mode, images that are not 3 x H x W);
+        generator draws are consumed exactly as the unfused path would.  Images that need the resize of :151-175 (every
+        native-size COCO image) are resized by the same launch (dib_normalize_resize_pad)."""
         if not (self.fused and self.normalize_images and not self.crop_images and images):
             return None
         first = images[0]
@@ -123,24 +124,26 @@ class GeneralizedRCNNTransform(nn.Module):
             return None
         if any(i.dim() != 3 or i.shape[0] != 3 or i.dtype != first.dtype or not i.is_cuda for i in images):
             return None
-        state = torch.get_rng_state() if self.training else None
-        sizes = [self._target_size() for _ in images]
-        if any(self._scale(int(i.shape[-2]), int(i.shape[-1]), s) != 1.0 for i, s in zip(images, sizes)):
-            if state is not None:
-                torch.set_rng_state(state)        # the unfused path will make these draws itself
-            return None
+        sizes = [self._target_size() for _ in images]           # one generator draw per image when training, in image order
         from .. import blur_ops
         n = len(images)
         means = newMeans if newMeans is not None else np.tile(np.asarray(self.image_mean, dtype=np.float64), (n, 1))
         stds = newSTDs if newSTDs is not None else np.tile(np.asarray(self.image_std, dtype=np.float64), (n, 1))
         hw = [(int(i.shape[-2]), int(i.shape[-1])) for i in images]
-        Hp = int(math.ceil(max(h for h, _ in hw) / 32.0) * 32)
-        Wp = int(math.ceil(max(w for _, w in hw) / 32.0) * 32)
-        batch = blur_ops.normalize_pad(images, means, stds, Hp, Wp, getattr(self, "channels_last", False))
+        out_hw = []
+        for (h, w), s in zip(hw, sizes):
+            scale = self._scale(h, w, s)
+            # F.interpolate(..., scale_factor=scale, recompute_scale_factor=True): output size int(size * scale), per dimension
+            out_hw.append((h, w) if scale == 1.0 else (int(h * scale), int(w * scale)))
+        if any(oh <= 0 or ow <= 0 for oh, ow in out_hw):
+            return None                                         # degenerate sliver: let interpolate raise what it raises
+        Hp = int(math.ceil(max(h for h, _ in out_hw) / 32.0) * 32)
+        Wp = int(math.ceil(max(w for _, w in out_hw) / 32.0) * 32)
+        batch = blur_ops.normalize_pad(images, means, stds, Hp, Wp, getattr(self, "channels_last", False), out_sizes=out_hw)
         if targets is not None:
-            for t, (h, w) in zip(targets, hw):
-                t["boxes"] = resize_boxes(t["boxes"], (h, w), (h, w))
-        return ImageList(batch, hw), targets
+            for t, src, dst in zip(targets, hw, out_hw):
+                t["boxes"] = resize_boxes(t["boxes"], src, dst)
+        return ImageList(batch, out_hw), targets
 
     def forward(self, images, targets=None, newMeans=None, newSTDs=None):
         images = list(images)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE); 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -132,6 +132,17 @@ int dib_blur_step_release(void);
 int dib_normalize_pad(const void *const *in_dev, int dtype, const int *H, const int *W, int B,
                       const float *mean, const float *std, float *out_dev, int Hp, int Wp,
                       int channels_last, void *stream);
+
+/* The same epilogue for batches whose images need the detector's internal resize (every native-size COCO batch: the reference
+ * blurs before the model resizes, engine.py:101 -> models/net_transforms.py:151-175): float conversion, per-image normalisation,
+ * bilinear resize to Ho[i] x Wo[i] -- torch.nn.functional.interpolate(mode="bilinear", recompute_scale_factor=True,
+ * align_corners=False) as ATen computes it on the GPU, the scale recomputed from the integer sizes -- and the zero-padded batch,
+ * one launch.  Ho / Wo: host arrays, the output size of image i (the caller's int(H * scale), net_transforms.py:36-46,167);
+ * an image with Ho == H and Wo == W is not interpolated (the reference skips the call at scale factor 1).  Everything else as
+ * dib_normalize_pad.  Bit-identical to the unfused GPU path; within 2e-6 of the reference's CPU result. */
+int dib_normalize_resize_pad(const void *const *in_dev, int dtype, const int *H, const int *W, const int *Ho, const int *Wo, int B,
+                             const float *mean, const float *std, float *out_dev, int Hp, int Wp, int channels_last,
+                             void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Box growth and clamping: utils.py:360-392 (`expand_targets`, one image) and utils.py:395-434

@@ -43,10 +43,13 @@ def test_ddp_gradients_equal_the_bare_model_over_one_rank_rccl(tmp_path, fused):
     assert r["fused"] is fused and len(r["steps"]) == 2
     for s in r["steps"]:
         assert s["all_finite"] and s["tensors"] > 80
-        bound = max(1e-5, 3.0 * s["bare_vs_bare_max"])
+        # step 0 (identical weights, deterministic forward): 1e-5 of every tensor's norm (measured 1.5e-6, the same as two bare
+        # runs).  step 1: the copies' weights differ by ~1e-6 after the first update, a few ReLU masks flip (measured
+        # 5e-4..2e-3, again the same between two bare runs): 5e-3, or three times the bare models' own spread
+        bound = 1e-5 if s["step"] == 0 else max(5e-3, 3.0 * s["bare_vs_bare_max"])
         assert s["ddp_vs_bare_max"] <= bound, s
-        assert s["bare_vs_bare_max"] <= 5e-2, s                 # the yardstick itself is sane
-        assert abs(s["loss"]["ddp"] - s["loss"]["bare"]) <= 1e-4 * abs(s["loss"]["bare"]), s
+        assert s["bare_vs_bare_max"] <= (1e-5 if s["step"] == 0 else 2e-2), s         # the yardstick itself
+        assert abs(s["loss"]["ddp"] - s["loss"]["bare"]) <= 1e-5 * abs(s["loss"]["bare"]), s
     assert r["steps"][1]["vs_previous_step_min"] > 1e-2
     assert r["weights_ddp_vs_bare_max"] <= 1e-4
 

@@ -54,14 +54,84 @@ def test_ragged_batch_and_default_statistics():
         blur_ops.normalize_pad(imgs, [MEAN] * 3, [STD] * 3, 32, 96)
 
 
-def test_resize_needed_falls_back_to_the_unfused_path():
-    imgs = _batch(torch.float16, [(50, 70), (60, 45)])
-    t = GeneralizedRCNNTransform(64, 100, MEAN, STD, training=False)
-    il, _ = t(imgs, None)
-    u = GeneralizedRCNNTransform(64, 100, MEAN, STD, training=False)
-    u.fused = False
-    il2, _ = u([i.float() for i in imgs], None)
-    assert torch.equal(il.tensors, il2.tensors) and il.image_sizes == il2.image_sizes
+COCO_SIZES = [(480, 640), (427, 640), (640, 480), (375, 500), (333, 500), (640, 428), (500, 375), (612, 612)]
+
+
+def _contraction(on):
+    import ctypes
+    from detectinblur_amd import _lib
+    l = _lib.lib()
+    l.dib_debug_set_resize_contraction.argtypes = [ctypes.c_int]
+    l.dib_debug_set_resize_contraction.restype = None
+    l.dib_debug_set_resize_contraction(int(on))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("training", [False, True])
+def test_fused_resize_equals_unfused_bit_for_bit(dtype, channels_last, training):
+    """Native-size COCO batches (the reference blurs before the model resizes, engine.py:101): float + normalise + bilinear
+    resize (min side 800 / max side 1333, recompute_scale_factor=True, align_corners=False) + zero-padded batch in ONE launch
+    (dib_normalize_resize_pad) against the module-by-module path -- which IS torch's own interpolate on the GPU: equal bit
+    for bit, sizes, boxes and generator state included; a multi-scale training transform draws one size per image."""
+    imgs = _batch(dtype, COCO_SIZES, seed=4)
+    n = len(imgs)
+    means = np.array([MEAN] * (n - 1) + [[0.5, 0.4, 0.3]])
+    stds = np.array([STD] * (n - 2) + [[0.11716, 0.11548, 0.11734], [0.2, 0.25, 0.3]])
+    tg = [{"boxes": torch.tensor([[1.0, 2.0, 300.0, 240.0], [50.5, 60.25, 200.0, 333.0]]).cuda()} for _ in imgs]
+    out = {}
+    for fused in (True, False):
+        t = GeneralizedRCNNTransform((640, 704, 800) if training else 800, 1333, MEAN, STD, training=training)
+        t.fused, t.channels_last = fused, channels_last
+        torch.manual_seed(3)
+        il, res = t([i.clone() for i in imgs], [dict(d) for d in tg], newMeans=means, newSTDs=stds)
+        out[fused] = (il.tensors, il.image_sizes, [d["boxes"] for d in res], torch.rand(1).item())
+    a, b = out[True], out[False]
+    assert a[0].dtype == torch.float32 and a[0].shape == b[0].shape and a[0].shape[2] % 32 == 0 and a[0].shape[3] % 32 == 0
+    assert a[0].is_contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    assert a[1] == b[1] and a[3] == b[3]                                         # sizes, generator state
+    if not training:
+        assert a[1][0] == (800, 1066) and a[1][2] == (1066, 800) and a[1][7] == (800, 800)
+    assert torch.equal(a[0], b[0])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    for k, (h, w) in enumerate(a[1]):                                            # the padding is zero
+        assert float(a[0][k, :, h:, :].abs().max() if h < a[0].shape[2] else 0.0) == 0.0
+        assert float(a[0][k, :, :, w:].abs().max() if w < a[0].shape[3] else 0.0) == 0.0
+
+
+def test_fused_resize_downscale_mixed_with_unit_scale_and_tiny_images():
+    """max-side-limited downscale (1500 x 2600 -> 769 x 1333), an image already at scale 1 in the same batch (not
+    interpolated), 1-pixel-wide and 2 x 2 images (the h1p / w1p edge clamps)."""
+    imgs = _batch(torch.float16, [(1500, 2600), (800, 1333), (3, 1), (2, 2), (1, 5)], seed=9)
+    out = {}
+    for fused in (True, False):
+        t = GeneralizedRCNNTransform(800, 1333, MEAN, STD, training=False)
+        t.fused, t.channels_last = fused, True
+        il, _ = t([i.clone() for i in imgs], None)
+        out[fused] = il
+    assert out[True].image_sizes == out[False].image_sizes and out[True].image_sizes[0] == (769, 1333) and out[True].image_sizes[1] == (800, 1333)
+    assert torch.equal(out[True].tensors, out[False].tensors)
+
+
+def test_the_uncontracted_variant_is_not_what_aten_computes():
+    """The kernel restates ATen's bilinear arithmetic WITH hipcc's default contraction (a * b + c * d = fma(a, b, c * d)); the
+    plain expression (what the CPU computes) differs from the eager GPU path: the source index `scale * (x + 0.5) - 0.5` is
+    rounded once instead of twice, which moves the interpolation weight by an ulp of the INDEX (6e-5 at x ~ 1000), i.e. the
+    result by ~1e-4 of the local contrast at full size -- evidence that the contraction pattern matters and that the shipped
+    one is ATen's.  (The reference-generated goldens of tests/test_net_transforms.py are 64..100 pixels wide: 2e-6 there.)"""
+    imgs = _batch(torch.float32, COCO_SIZES[:3], seed=4)
+    t = GeneralizedRCNNTransform(800, 1333, MEAN, STD, training=False)
+    t.fused = False
+    want = t([i.clone() for i in imgs], None)[0].tensors
+    t.fused = True
+    try:
+        _contraction(False)
+        plain = t([i.clone() for i in imgs], None)[0].tensors
+    finally:
+        _contraction(True)
+    fused = t([i.clone() for i in imgs], None)[0].tensors
+    assert torch.equal(fused, want)
+    assert not torch.equal(plain, want) and float((plain - want).abs().max()) <= 1e-3
 
 
 def test_train_step_is_identical_with_and_without_the_fused_epilogue():
