@@ -5,7 +5,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdib_host.so")
+# DIB_HOST_LIB: another build of the same library (the sanitizer build of `make -C detectinblur_amd/csrc asan`,
+# tests/test_host_asan.py)
+LIB_PATH = os.environ.get("DIB_HOST_LIB") or os.path.join(_HERE, "libdib_host.so")
 
 
 class MT19937(ctypes.Structure):
