@@ -554,17 +554,9 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
 }
 
-// Round-4 experiment ("blur store fused with the epilogue"): OUT32 stores float((acc - mean) / std) into the
-// detector's planar fp32 batch instead of the fp16 image -- the blur and dib_normalize_pad in one kernel.
-struct NormArgs {
-  float mean[MAX_BATCH][4], std[MAX_BATCH][4];
-  int Hp, Wp;
-  int nhwc;   // 1: channels-last batch [B][Hp][Wp][3] (what the detector reads); the launch then orders tiles channel-fastest
-};
-
-template <int ACC, bool OUT32 = false>
+template <int ACC>
 __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
-                                                   unsigned *lds, const NormArgs *na = nullptr, int img = 0) {
+                                                   unsigned *lds) {
 #pragma clang fp contract(off)
   constexpr int GQ = LROWS / NW;              // LDS rows a wave fills (11)
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -682,30 +674,7 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   }
   // ---- store: a store instruction writes 32 columns of row y (lanes 0-31) and of row y + 4 (lanes 32-63); lanes
   // outside the image get an out-of-range buffer offset and are dropped by the range check ----------------------------
-  if constexpr (OUT32) {
-    const int Hp = na->Hp, Wp = na->Wp;
-    const float m = na->mean[img][ch], sd = na->std[img][ch];
-    const int nhwc = na->nhwc;
-    const unsigned long long a = (unsigned long long)d.out + (nhwc ? (unsigned long long)ch * 4ull : (unsigned long long)ch * Hp * Wp * 4ull);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, Hp * Wp * 4 * (nhwc ? 3 : 1), 0x00020000);
-    const int sl = fresh_lane();
-    const int yl = y0 + wave * 8 + (sl >> 5) * 4, xl = x0 + (sl & 31);
-    const unsigned px = nhwc ? 12u : 4u;      // bytes between horizontally adjacent pixels of one channel
-    const unsigned base = (unsigned)(yl * Wp + xl) * px, oob = 0x7ffffff0u;
-    const bool inside = x0 + QTILE_W <= W && y0 + TH <= H;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool row_ok = inside || yl + i < H;
-      const unsigned ro = base + (unsigned)(i * Wp) * px;
-      const float f0 = ((float)acc[2 * i].x - m) / sd, f1 = ((float)acc[2 * i].y - m) / sd;
-      const float f2 = ((float)acc[2 * i + 1].x - m) / sd, f3 = ((float)acc[2 * i + 1].y - m) / sd;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, f0), out_rsrc, row_ok && (inside || xl < W) ? ro : oob, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, f1), out_rsrc, row_ok && (inside || xl + 32 < W) ? ro + 32u * px : oob, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, f2), out_rsrc, row_ok && (inside || xl + 64 < W) ? ro + 64u * px : oob, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, f3), out_rsrc, row_ok && (inside || xl + 96 < W) ? ro + 96u * px : oob, 0, 0);
-    }
-  } else {
+  {
     const __amdgpu_buffer_rsrc_t out_rsrc = plane_rsrc(d.out, ch, H, W);
     const int sl = fresh_lane();
     const int yl = y0 + wave * 8 + (sl >> 5) * 4, xl = x0 + (sl & 31);
@@ -790,27 +759,6 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch) 
     }
   }
 #endif
-}
-
-template <int ACC, int KC>
-__global__ __launch_bounds__(256, 8) void blur_quad_f16_norm_kernel(BlurBatch batch, NormArgs na) {
-  constexpr int K = KC;
-  extern __shared__ unsigned nlds[];
-  const ImageDesc d = batch.img[blockIdx.y];
-  const int per_ch = d.tiles_x * d.tiles_y;
-  int local;
-  if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
-  int ch;
-  if (na.nhwc) {   // channel fastest: the three workgroups that complete a pixel's 12 bytes are dispatched back to back on one XCD
-    const int t = local / 3;
-    ch = local - 3 * t;
-    local = t;
-  } else {
-    ch = magic_div(local, d.inv_per_ch);
-    local -= ch * per_ch;
-  }
-  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  blur_quad_tile_f16<ACC, true>(d, d.tab, K, ch, tx, ty, nlds, &na, blockIdx.y);
 }
 
 template <int ACC>
@@ -1069,41 +1017,6 @@ extern "C" int dib_sparse_blur_generic(const void *in_dev, void *out_dev, int C,
     hipLaunchKernelGGL((blur_generic_kernel<__half, DIB_ACC_FP32>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
   else  // dtype 3: fp16 image, DIB_ACC_FMA16 arithmetic
     hipLaunchKernelGGL((blur_generic_kernel<__half, DIB_ACC_FMA16>), dim3(blocks), dim3(256), 0, s, g, (const int *)table_dev, K);
-  DIB_HIP_CHECK(hipGetLastError());
-  return DIB_OK;
-}
-
-// Round-4 experiment hook (not part of the drop-in boundary): the default blur kernel with the fused fp32 normalising store.
-// All images 3 x H x W fp16 of one size, K = 128, bit-exact accumulation; out_dev: [B][3][Hp][Wp] fp32 planar (padding
-// untouched); mean / std: host [B][3].
-extern "C" int dib_debug_blur_normalized(const void *const *in_dev, float *out_dev, int H, int W, const int *table_index, int B,
-                                         void *tables_dev, const float *mean, const float *std, int Hp, int Wp, int nhwc, void *stream) {
-  if (B <= 0 || B > MAX_BATCH) { set_error("dib_debug_blur_normalized: 1..%d images", MAX_BATCH); return DIB_EINVAL; }
-  if (int rc = prepare_device()) return rc;
-  DIB_HIP_CHECK(opt_in((blur_quad_f16_norm_kernel<DIB_ACC_BITEXACT, 128>), QLDS_BYTES));
-  BlurBatch tiled;
-  NormArgs na;
-  na.Hp = Hp; na.Wp = Wp; na.nhwc = nhwc ? 1 : 0;
-  tiled.n = 0;
-  int tiles = 0;
-  for (int i = 0; i < B; ++i) {
-    ImageDesc d;
-    d.in = in_dev[i]; d.out = out_dev + (size_t)i * 3 * Hp * Wp; d.C = 3; d.H = H; d.W = W; d.table = table_index[i];
-    d.tiles_x = (W + QTILE_W - 1) / QTILE_W; d.tiles_y = (H + TH - 1) / TH;
-    d.inv_per_ch = magic_inverse((unsigned)(d.tiles_x * d.tiles_y)); d.inv_tiles_x = magic_inverse((unsigned)d.tiles_x);
-    d.tab = (const int *)tables_dev + (size_t)table_index[i] * table_words(128);
-    d.tile_begin = tiles; tiled.tile_begin[i] = tiles;
-    tiles += 3 * d.tiles_x * d.tiles_y;
-    tiled.img[tiled.n++] = d;
-    for (int c = 0; c < 3; ++c) { na.mean[i][c] = mean[i * 3 + c]; na.std[i][c] = std[i * 3 + c]; }
-    na.mean[i][3] = 0.f; na.std[i][3] = 1.f;
-  }
-  for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
-  tiled.total_tiles = tiles; tiled.xcd_bands = 1;
-  const int T = 3 * tiled.img[0].tiles_x * tiled.img[0].tiles_y;
-  int longest = 0;
-  for (int x = 0; x < 8; ++x) { const int len = (((x + 1) * T) >> 3) - ((x * T) >> 3); longest = len > longest ? len : longest; }
-  hipLaunchKernelGGL((blur_quad_f16_norm_kernel<DIB_ACC_BITEXACT, 128>), dim3(8 * longest, tiled.n), dim3(256), QLDS_BYTES, (hipStream_t)stream, tiled, na);
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }

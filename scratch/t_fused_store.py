@@ -1,4 +1,6 @@
-"""Round-4 experiment: the blur's store fused with the epilogue (float + normalise, planar fp32 batch) vs the two kernels
+"""NEEDS THE BUILD OF COMMIT 6c83371 (`git show 6c83371:detectinblur_amd/csrc/dib_blur.hip`: blur_quad_f16_norm_kernel +
+dib_debug_blur_normalized; removed from the product again, result in profiles/r4_fused_store.txt).
+Round-4 experiment: the blur's store fused with the epilogue (float + normalise, planar fp32 batch) vs the two kernels
 (blur -> fp16 images, dib_normalize_pad -> fp32 batch) on the BASELINE batch; bit-identity on the image region."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
