@@ -87,6 +87,9 @@ _SIGNATURES = {
                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "dib_stem_pool_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_void_p]),
+    "dib_fold_bn_multi": (ctypes.c_int, [_c_void_pp, _c_void_pp, _c_void_pp, _c_void_pp, _c_void_pp, _c_int_p, _c_int_p, ctypes.c_int,
+                                         ctypes.c_float, _c_void_pp, _c_void_pp, _c_void_pp, ctypes.c_void_p]),
+    "dib_scale_rows_multi": (ctypes.c_int, [_c_void_pp, _c_void_pp, _c_int_p, _c_int_p, ctypes.c_int, _c_void_pp, ctypes.c_void_p]),
     "dib_post_ops": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_double, ctypes.c_ulonglong, ctypes.c_double, ctypes.c_void_p]),
     "dib_jpeg_roundtrip": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -190,6 +190,78 @@ __global__ __launch_bounds__(256) void bias_act_scalar_kernel(float *__restrict_
   }
 }
 
+
+// ---- frozen batch-norm folds of many convolutions in ONE launch --------------------------------------------------------------
+// Training folds every trunk convolution's frozen batch-norm into its weight each step (the weights move): per convolution
+// that is five tiny launches forward (add eps, rsqrt, two multiplies, a subtract, the weight multiply) and one backward, 53
+// times -- ~320 launches of ~5 us that the GPU waits for (profiles/r4_train_step_conv.txt).  Here: up to FOLD_MAX pairs per launch.
+// Same operations in the same order as the tensor expressions (scale = bn_w * rsqrt(var + eps); shift = bn_b - mean * scale;
+// wf = w * scale[co]), so the results are bit-identical to the per-convolution path (tests/test_detector_ops.py).
+constexpr int FOLD_MAX = 32;
+struct FoldArgs {
+  const float *w[FOLD_MAX], *bn_w[FOLD_MAX], *bn_b[FOLD_MAX], *mean[FOLD_MAX], *var[FOLD_MAX];
+  float *wf[FOLD_MAX], *scale[FOLD_MAX], *shift[FOLD_MAX];
+  int inner[FOLD_MAX];            // elements per output channel (Ci * kh * kw)
+  long long count[FOLD_MAX];      // Co * inner
+  int block_start[FOLD_MAX + 1];  // first 1024-element block of pair k
+  int n;
+  float eps;
+};
+
+// pass 1: one thread per output channel.  torch's rsqrt kernel on this platform returns the correctly rounded value (checked
+// against float(rsqrt(double(x))) on 200,000 samples, scratch/t_rsq.py) where rsqrtf() is v_rsq_f32's 1-ulp approximation
+// (12 % of the samples differ): the double-precision form below reproduces torch's bits.
+__global__ __launch_bounds__(256) void fold_scale_shift_kernel(FoldArgs a) {
+#pragma clang fp contract(off)
+  const int k = blockIdx.y;
+  const int co = blockIdx.x * 256 + threadIdx.x;
+  if (k >= a.n || (long long)co * a.inner[k] >= a.count[k]) return;
+  const float v = a.var[k][co] + a.eps;
+  const float sc = a.bn_w[k][co] * (float)(1.0 / sqrt((double)v));
+  a.scale[k][co] = sc;
+  a.shift[k][co] = a.bn_b[k][co] - a.mean[k][co] * sc;
+}
+
+// pass 2: wf = w * scale[co], 1024 consecutive elements of one weight per block
+__global__ __launch_bounds__(256) void fold_bn_multi_kernel(FoldArgs a) {
+#pragma clang fp contract(off)
+  int k = 0;
+  while (k + 1 < a.n && (int)blockIdx.x >= a.block_start[k + 1]) ++k;
+  const long long base = (long long)((int)blockIdx.x - a.block_start[k]) * 1024;
+  const int inner = a.inner[k];
+  const float *w = a.w[k];
+  const float *sc = a.scale[k];
+  float *wf = a.wf[k];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long e = base + j * 256 + threadIdx.x;
+    if (e >= a.count[k]) break;
+    wf[e] = w[e] * sc[(int)(e / inner)];
+  }
+}
+
+struct ScaleRowsArgs {
+  const float *g[FOLD_MAX], *scale[FOLD_MAX];
+  float *dw[FOLD_MAX];
+  int inner[FOLD_MAX];
+  long long count[FOLD_MAX];
+  int block_start[FOLD_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void scale_rows_multi_kernel(ScaleRowsArgs a) {
+  int k = 0;
+  while (k + 1 < a.n && (int)blockIdx.x >= a.block_start[k + 1]) ++k;
+  const long long base = (long long)((int)blockIdx.x - a.block_start[k]) * 1024;
+  const int inner = a.inner[k];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long e = base + j * 256 + threadIdx.x;
+    if (e >= a.count[k]) break;
+    a.dw[k][e] = a.g[k][e] * a.scale[k][(int)(e / inner)];
+  }
+}
+
 }  // namespace dib
 
 using namespace dib;
@@ -343,6 +415,60 @@ static int bias_act_impl(float *x_dev, const float *bias_dev, const float *resid
   if (residual_dev) { if (relu) DIB_LAUNCH(true, true); else DIB_LAUNCH(true, false); }
   else { if (relu) DIB_LAUNCH(false, true); else DIB_LAUNCH(false, false); }
 #undef DIB_LAUNCH
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
+
+// Frozen batch-norm folds of n convolutions (any n; FOLD_MAX pairs per launch).  Host arrays of n device pointers / sizes:
+// w[k] [Co[k]][inner[k]] dense with the output channel outermost (contiguous OR channels-last weights), bn_* [Co[k]];
+// wf[k] receives the folded weight in w[k]'s element order, scale[k] / shift[k] [Co[k]].
+extern "C" int dib_fold_bn_multi(const float *const *w, const float *const *bn_w, const float *const *bn_b, const float *const *mean,
+                                 const float *const *var, const int *Co, const int *inner, int n, float eps, float *const *wf,
+                                 float *const *scale, float *const *shift, void *stream) {
+  if (n < 0 || (n > 0 && (!w || !bn_w || !bn_b || !mean || !var || !Co || !inner || !wf || !scale || !shift))) { set_error("dib_fold_bn_multi: null pointer or negative count"); return DIB_EINVAL; }
+  for (int k0 = 0; k0 < n; k0 += FOLD_MAX) {
+    FoldArgs a;
+    a.n = n - k0 < FOLD_MAX ? n - k0 : FOLD_MAX;
+    a.eps = eps;
+    int blocks = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const int k = k0 + i;
+      if (!w[k] || !bn_w[k] || !bn_b[k] || !mean[k] || !var[k] || !wf[k] || !scale[k] || !shift[k] || Co[k] <= 0 || inner[k] <= 0) { set_error("dib_fold_bn_multi: pair %d has a null pointer or an empty shape", k); return DIB_EINVAL; }
+      a.w[i] = w[k]; a.bn_w[i] = bn_w[k]; a.bn_b[i] = bn_b[k]; a.mean[i] = mean[k]; a.var[i] = var[k];
+      a.wf[i] = wf[k]; a.scale[i] = scale[k]; a.shift[i] = shift[k];
+      a.inner[i] = inner[k]; a.count[i] = (long long)Co[k] * inner[k];
+      a.block_start[i] = blocks;
+      blocks += (int)((a.count[i] + 1023) / 1024);
+    }
+    for (int i = a.n; i <= FOLD_MAX; ++i) a.block_start[i] = blocks;
+    int max_co = 0;
+    for (int i = 0; i < a.n; ++i) max_co = Co[k0 + i] > max_co ? Co[k0 + i] : max_co;
+    hipLaunchKernelGGL(fold_scale_shift_kernel, dim3((unsigned)((max_co + 255) / 256), (unsigned)a.n), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(fold_bn_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
+
+// The backward of those folds: dw[k][co][...] = g[k][co][...] * scale[k][co] (the gradient of w * scale[co] with respect to w).
+extern "C" int dib_scale_rows_multi(const float *const *g, const float *const *scale, const int *Co, const int *inner, int n,
+                                    float *const *dw, void *stream) {
+  if (n < 0 || (n > 0 && (!g || !scale || !Co || !inner || !dw))) { set_error("dib_scale_rows_multi: null pointer or negative count"); return DIB_EINVAL; }
+  for (int k0 = 0; k0 < n; k0 += FOLD_MAX) {
+    ScaleRowsArgs a;
+    a.n = n - k0 < FOLD_MAX ? n - k0 : FOLD_MAX;
+    int blocks = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const int k = k0 + i;
+      if (!g[k] || !scale[k] || !dw[k] || Co[k] <= 0 || inner[k] <= 0) { set_error("dib_scale_rows_multi: tensor %d has a null pointer or an empty shape", k); return DIB_EINVAL; }
+      a.g[i] = g[k]; a.scale[i] = scale[k]; a.dw[i] = dw[k];
+      a.inner[i] = inner[k]; a.count[i] = (long long)Co[k] * inner[k];
+      a.block_start[i] = blocks;
+      blocks += (int)((a.count[i] + 1023) / 1024);
+    }
+    for (int i = a.n; i <= FOLD_MAX; ++i) a.block_start[i] = blocks;
+    hipLaunchKernelGGL(scale_rows_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  }
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }

@@ -332,6 +332,103 @@ class _DownEntry(torch.autograd.Function):
         return (dx if need_x else None), (dw1 if need_w1 else None), (dwd if need_wd else None), None, None
 
 
+# Training re-folds every trunk convolution's frozen batch-norm each step (the weights move).  Per convolution that is five
+# tiny launches forward and one backward, 53 times: ~320 launches of ~5 us each that the GPU sits through.  FOLD_ALL folds
+# every trainable pair of the body in ONE launch per 32 at the start of its forward pass (dib_fold_bn_multi; backward:
+# dib_scale_rows_multi), bit-identical to the per-convolution expressions (the same operations in the same order).
+FOLD_ALL = True
+
+
+class _FoldAll(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pairs, *weights):
+        from .. import _lib
+        n = len(weights)
+        dev = weights[0].device
+        cos = [int(w.shape[0]) for w in weights]
+        inner = [int(w.numel() // w.shape[0]) for w in weights]
+        wfs = [torch.empty_like(w) for w in weights]                     # preserve_format: the fold keeps the weight's layout
+        flat = torch.empty(2 * sum(cos), dtype=torch.float32, device=dev)
+        scales, shifts, off = [], [], 0
+        for c in cos:
+            scales.append(flat[off:off + c]); shifts.append(flat[off + c:off + 2 * c]); off += 2 * c
+        P = _lib.ptr_array
+        bns = [bn for _, bn in pairs]
+        _lib.check(_lib.lib().dib_fold_bn_multi(
+            P([w.data_ptr() for w in weights]), P([b.weight.data_ptr() for b in bns]), P([b.bias.data_ptr() for b in bns]),
+            P([b.running_mean.data_ptr() for b in bns]), P([b.running_var.data_ptr() for b in bns]), _lib.int_array(cos),
+            _lib.int_array(inner), n, float(bns[0].eps), P([t.data_ptr() for t in wfs]), P([t.data_ptr() for t in scales]),
+            P([t.data_ptr() for t in shifts]), torch.cuda.current_stream().cuda_stream))
+        ctx.save_for_backward(flat)
+        ctx.meta = (cos, inner)
+        ctx.mark_non_differentiable(*shifts)
+        return tuple(wfs) + tuple(shifts)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from .. import _lib
+        (flat,) = ctx.saved_tensors
+        cos, inner = ctx.meta
+        n = len(cos)
+        gs, ks, off, offs = [], [], 0, []
+        for k, c in enumerate(cos):
+            offs.append(off)
+            off += 2 * c
+        dws = [None] * n
+        for k in range(n):
+            g = grads[k]
+            if g is None or not ctx.needs_input_grad[1 + k]:
+                continue
+            # dense, output channel outermost (contiguous or channels-last), as the forward pass saw the weight
+            if not (g.is_contiguous() or g.is_contiguous(memory_format=torch.channels_last)):
+                g = g.contiguous()
+            gs.append(g); ks.append(k)
+        if ks:
+            outs = [torch.empty_like(g) for g in gs]
+            P = _lib.ptr_array
+            _lib.check(_lib.lib().dib_scale_rows_multi(
+                P([g.data_ptr() for g in gs]), P([flat.data_ptr() + 4 * offs[k] for k in ks]), _lib.int_array([cos[k] for k in ks]),
+                _lib.int_array([inner[k] for k in ks]), len(ks), P([o.data_ptr() for o in outs]), torch.cuda.current_stream().cuda_stream))
+            for k, o in zip(ks, outs):
+                dws[k] = o
+        return (None,) + tuple(dws)
+
+
+def _begin_step_folds(body, x):
+    """Fold every trainable (convolution, frozen batch-norm) pair of `body` at once and park the results on the convolutions
+    for the duration of this forward pass; returns the list to hand to _end_step_folds (None: nothing parked)."""
+    if not (FOLD_ALL and FOLD_FROZEN_BN and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32):
+        return None
+    pairs = []
+    for conv, bn in _fold_pairs(body):
+        w = conv.weight
+        if (w.requires_grad and isinstance(bn, FrozenBatchNorm2d) and conv.bias is None and w.is_cuda and w.dtype == torch.float32
+                and (w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)) and bn.weight.is_cuda):
+            pairs.append((conv, bn))
+    if not pairs or len({float(bn.eps) for _, bn in pairs}) != 1:
+        return None
+    outs = _FoldAll.apply(pairs, *[conv.weight for conv, _ in pairs])
+    n = len(pairs)
+    for k, (conv, _) in enumerate(pairs):
+        conv.__dict__["_dib_step_fold"] = (outs[k], outs[n + k])
+    return pairs
+
+
+def _end_step_folds(pairs):
+    for conv, _ in pairs or ():
+        conv.__dict__.pop("_dib_step_fold", None)
+
+
+def _train_fold(conv, bn):
+    """(weight * scale, shift) of a trainable convolution + frozen batch-norm pair for THIS forward pass: the parked result of
+    _begin_step_folds when there is one, the per-convolution expressions otherwise (same values)."""
+    hit = conv.__dict__.get("_dib_step_fold")
+    if hit is not None:
+        return hit
+    scale, shift = bn.affine()
+    return conv.weight * scale.reshape(-1, 1, 1, 1), shift
+
+
 def down_entry(x, conv1, bn1, convd, bnd):
     """(relu(bn1(conv1(x))), bnd(convd(x))) for the first block of a stage, or None where the fused node does not apply."""
     if not (BLOCK_ENTRY and FUSE_EPILOGUE and FOLD_FROZEN_BN and isinstance(bn1, FrozenBatchNorm2d) and isinstance(bnd, FrozenBatchNorm2d)
@@ -342,9 +439,9 @@ def down_entry(x, conv1, bn1, convd, bnd):
             and x.is_contiguous(memory_format=torch.channels_last) and not (x.data_ptr() & 15) and torch.is_grad_enabled()
             and x.requires_grad):
         return None
-    s1, t1 = bn1.affine()
-    sd, td = bnd.affine()
-    a, d = _DownEntry.apply(x, conv1.weight * s1.reshape(-1, 1, 1, 1), convd.weight * sd.reshape(-1, 1, 1, 1), conv1, convd)
+    w1, t1 = _train_fold(conv1, bn1)
+    wd, td = _train_fold(convd, bnd)
+    a, d = _DownEntry.apply(x, w1, wd, conv1, convd)
     return bias_act(a, t1, None, True), bias_act(d, td, None, False)
 
 
@@ -357,8 +454,8 @@ def block_entry(x, conv, bn):
             and x.is_contiguous(memory_format=torch.channels_last) and not (x.data_ptr() & 15) and torch.is_grad_enabled()
             and (x.requires_grad or conv.weight.requires_grad)):
         return None
-    scale, shift = bn.affine()
-    out, skip = _BlockEntry.apply(x, conv.weight * scale.reshape(-1, 1, 1, 1), getattr(x, "_dib_relu_state", None), conv)
+    weight, shift = _train_fold(conv, bn)
+    out, skip = _BlockEntry.apply(x, weight, getattr(x, "_dib_relu_state", None), conv)
     return bias_act(out, shift, None, True), skip
 
 
@@ -454,8 +551,7 @@ def conv_bn(x, conv, bn, relu=False, residual=None):
     into the weights and its shift into the fused epilogue."""
     if FOLD_FROZEN_BN and isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
         if torch.is_grad_enabled() and conv.weight.requires_grad:
-            scale, shift = bn.affine()
-            weight = conv.weight * scale.reshape(-1, 1, 1, 1)
+            weight, shift = _train_fold(conv, bn)
         else:
             weight, shift = _folded(conv, bn)
         y = _WideOut1x1.apply(x, weight) if _wide_out(x, conv) else conv1x1(x, weight, None, conv)
@@ -530,8 +626,7 @@ def stem(x, conv, bn):
     if (FUSE_STEM_POOL and FUSE_EPILOGUE and FOLD_FROZEN_BN and isinstance(bn, FrozenBatchNorm2d) and conv.bias is None and x.is_cuda
             and x.dtype == torch.float32 and conv.out_channels % 4 == 0):
         if torch.is_grad_enabled() and conv.weight.requires_grad:
-            scale, shift = bn.affine()
-            weight = conv.weight * scale.reshape(-1, 1, 1, 1)
+            weight, shift = _train_fold(conv, bn)
         else:
             weight, shift = _folded(conv, bn)
         y = conv1x1(x, weight, None, conv)
@@ -563,11 +658,15 @@ class ResNet50Body(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = stem(x, self.conv1, self.bn1)
-        c2 = self.layer1(x)
-        c3 = self.layer2(c2)
-        c4 = self.layer3(c3)
-        c5 = self.layer4(c4)
+        parked = _begin_step_folds(self, x)
+        try:
+            x = stem(x, self.conv1, self.bn1)
+            c2 = self.layer1(x)
+            c3 = self.layer2(c2)
+            c4 = self.layer3(c3)
+            c5 = self.layer4(c4)
+        finally:
+            _end_step_folds(parked)
         return [c2, c3, c4, c5]
 
 

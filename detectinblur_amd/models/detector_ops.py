@@ -31,6 +31,35 @@ def box_iou(a, b):
     return inter / (box_area(a)[:, None] + box_area(b)[None, :] - inter)
 
 
+def pad_boxes(boxes_per_image, width=None):
+    """Ragged per-image box lists -> ([N, G, 4] padded with zeros, valid [N, G] bool); G = the longest list (at least 1).
+    Shapes are host knowledge: no device synchronisation."""
+    G = max([b.shape[0] for b in boxes_per_image] + [1]) if width is None else width
+    ref = boxes_per_image[0]
+    out = ref.new_zeros((len(boxes_per_image), G, 4))
+    for i, b in enumerate(boxes_per_image):
+        if b.shape[0]:
+            out[i, :b.shape[0]] = b
+    counts = torch.tensor([b.shape[0] for b in boxes_per_image])
+    valid = torch.arange(G)[None, :] < counts[:, None]
+    if ref.is_cuda:
+        valid = valid.pin_memory().to(ref.device, non_blocking=True)
+    return out, valid
+
+
+def box_iou_batched(a, b):
+    """[N, G, 4] x ([N, M, 4] or [M, 4]) -> [N, G, M]: `box_iou` of every image at once, the same arithmetic per pair."""
+    if b.dim() == 2:
+        b = b[None]
+    lt = torch.max(a[:, :, None, :2], b[:, None, :, :2])
+    rb = torch.min(a[:, :, None, 2:], b[:, None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    return inter / (area_a[:, :, None] + area_b[:, None, :] - inter)
+
+
 def clip_boxes_to_image(boxes, size):
     h, w = size
     x = boxes[..., 0::2].clamp(min=0, max=w)
@@ -102,6 +131,22 @@ class Matcher(object):
             restore = (quality == best_per_gt[:, None]).any(dim=0)       # a mask, not torch.where: no host sync
             matches = torch.where(restore, all_matches, matches)
         return matches
+
+
+def match_batched(matcher, quality, valid):
+    """`Matcher.__call__` for every image at once: quality [N, G, M] (IoU of padded ground truth x predictions), valid [N, G]
+    (False = padding row).  Returns matches [N, M] with the same values the per-image call gives on the valid rows; an image
+    without ground truth comes out all BELOW_LOW (its per-image call is skipped by the callers, who label such images 0)."""
+    q = torch.where(valid[:, :, None], quality, quality.new_full((), -1.0))      # padding never wins a maximum
+    vals, matches = q.max(dim=1)
+    all_matches = matches.clone() if matcher.allow_low else None
+    matches = torch.where(vals < matcher.low, matches.new_full((), Matcher.BELOW_LOW), matches)
+    matches = torch.where((vals >= matcher.low) & (vals < matcher.high), matches.new_full((), Matcher.BETWEEN), matches)
+    if matcher.allow_low:
+        best_per_gt = q.max(dim=2)[0]
+        restore = ((q == best_per_gt[:, :, None]) & valid[:, :, None]).any(dim=1)
+        matches = torch.where(restore, all_matches, matches)
+    return matches
 
 
 def sample_pos_neg(labels_per_image, batch_size, positive_fraction):

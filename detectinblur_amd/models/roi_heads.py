@@ -80,6 +80,43 @@ class RoIHeads(nn.Module):
         dtype, device = boxes.dtype, boxes.device
         gt_boxes = [t["boxes"].to(dtype) for t in targets]
         gt_labels = [t["labels"] for t in targets]
+        if not self.batched:
+            return self._select_per_image(boxes, ok, gt_boxes, gt_labels)
+        # every image at once (ground truth padded to the longest list, padding rows [0, 0, 1, 1] as in the per-image form):
+        # the per-image loop below is ~30 small launches per image that the host issues slower than the GPU runs them
+        N = boxes.shape[0]
+        gt, valid = ops.pad_boxes(gt_boxes)
+        G = gt.shape[1]
+        unit = _unit_boxes(1, boxes)[None].expand(N, G, 4)
+        pool_gt = torch.where(valid[..., None], gt, unit)
+        cands = torch.cat((boxes, pool_gt), dim=1)                                 # ground truth joins the pool
+        live = torch.cat((ok, valid), dim=1)
+        m = ops.match_batched(self.matcher, ops.box_iou_batched(gt, cands), valid)   # [N, P + G]
+        lab_pad = torch.zeros((N, G), dtype=torch.int64, device=device)
+        for i, gl in enumerate(gt_labels):
+            if gl.shape[0]:
+                lab_pad[i, :gl.shape[0]] = gl
+        lab = lab_pad.gather(1, m.clamp(min=0))
+        lab = torch.where(m == ops.Matcher.BELOW_LOW, lab.new_zeros(()), lab)
+        lab = torch.where(m == ops.Matcher.BETWEEN, lab.new_full((), -1), lab)
+        labels = torch.where(live, lab, lab.new_full((), -1))                       # padding is ignored by the sampler
+        matched = m.clamp(min=0)
+        S = self.batch_size_per_image
+        pos_idx, pos_ok, neg_idx, neg_ok = ops.sample_pos_neg_fixed(labels, S, self.positive_fraction)
+        sel, sel_ok = torch.cat([pos_idx, neg_idx], dim=1), torch.cat([pos_ok, neg_ok], dim=1)
+        # real samples first (foreground, then background, each in draw order), padding last; keep S
+        order = torch.argsort((~sel_ok).to(torch.int8), dim=1, stable=True)[:, :S]
+        sel, sel_ok = sel.gather(1, order), sel_ok.gather(1, order)
+        rois = cands.gather(1, sel[..., None].expand(-1, -1, 4))
+        labs = labels.gather(1, sel)
+        ref = gt.gather(1, matched.gather(1, sel)[..., None].expand(-1, -1, 4))      # images without boxes: zeros
+        reg = self.box_coder.encode(ref.reshape(-1, 4), rois.reshape(-1, 4))
+        return list(rois), labs.reshape(-1), reg, sel_ok.reshape(-1)
+
+    batched = True      # False: the per-image form below (the checker of tests/test_detector_ops.py)
+
+    def _select_per_image(self, boxes, ok, gt_boxes, gt_labels):
+        dtype, device = boxes.dtype, boxes.device
         g_max = max([g.shape[0] for g in gt_boxes] + [1])
         cands, labels, matched = [], [], []
         for b, o, g, gl in zip(boxes, ok, gt_boxes, gt_labels):

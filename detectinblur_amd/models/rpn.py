@@ -188,6 +188,22 @@ class RegionProposalNetwork(nn.Module):
         return self._filter(proposals, objectness, sizes, counts)
 
     def assign_targets(self, anchors, targets):
+        """labels (1 / 0 / -1) and matched ground-truth boxes per anchor and image.  All images at once (ground truth padded to
+        the longest list): the per-image form -- kept below as `assign_targets_per_image`, the checker -- is ~70 small launches
+        per image, 577 per step at b = 8, and the host issues them slower than the GPU runs them (profiles/r4_train_step_conv.txt)."""
+        same = all(a is anchors[0] for a in anchors)
+        if not same or not targets:
+            return self.assign_targets_per_image(anchors, targets)
+        a = anchors[0]
+        gt, valid = ops.pad_boxes([t["boxes"] for t in targets])
+        m = ops.match_batched(self.matcher, ops.box_iou_batched(gt, a), valid)                  # [N, A]
+        matched = gt.gather(1, m.clamp(min=0)[..., None].expand(-1, -1, 4))                   # images without boxes: zeros
+        lab = (m >= 0).to(torch.float32)
+        lab = torch.where(m == ops.Matcher.BELOW_LOW, lab.new_zeros(()), lab)
+        lab = torch.where(m == ops.Matcher.BETWEEN, lab.new_full((), -1.0), lab)               # ignored by the sampler
+        return lab, matched
+
+    def assign_targets_per_image(self, anchors, targets):
         labels, matched = [], []
         for a, t in zip(anchors, targets):
             gt = t["boxes"]
@@ -201,7 +217,7 @@ class RegionProposalNetwork(nn.Module):
             lab[m == ops.Matcher.BELOW_LOW] = 0.0
             lab[m == ops.Matcher.BETWEEN] = -1.0       # ignored by the sampler
             labels.append(lab)
-        return labels, matched
+        return torch.stack(labels), torch.stack(matched)
 
     def compute_loss(self, objectness, deltas, labels, regression_targets):
         """labels [N, A] (1 / 0 / -1), regression_targets [N, A, 4].  Fixed-size sampling + masked
@@ -231,8 +247,8 @@ class RegionProposalNetwork(nn.Module):
         losses = {}
         if self.training:
             assert targets is not None
-            labels, matched = self.assign_targets(anchors, targets)
-            reg_targets = [self.box_coder.encode(m, a) for m, a in zip(matched, anchors)]
-            obj, box = self.compute_loss(objectness, deltas, torch.stack(labels), torch.stack(reg_targets))
+            labels, matched = self.assign_targets(anchors, targets)                          # [N, A], [N, A, 4]
+            reg_targets = self.box_coder.encode(matched.reshape(-1, 4), torch.cat(anchors)).view(N, -1, 4)
+            obj, box = self.compute_loss(objectness, deltas, labels, reg_targets)
             losses = {"loss_objectness": obj, "loss_rpn_box_reg": box}
         return boxes, losses

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad, dib_fold_bn_multi, dib_scale_rows_multi; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -257,6 +257,19 @@ int dib_stem_pool_forward(const float *x_dev, const float *bias_dev, float *out_
                           void *stream);
 int dib_stem_pool_backward(const float *grad_out_dev, const unsigned short *arg_dev, float *grad_in_dev, int N, int H, int W, int C,
                            void *stream);
+
+/* Frozen batch-norm folds of n trunk convolutions in one launch per 32 (torchvision's FrozenBatchNorm2d behind every ResNet
+ * convolution, reference models/faster_rcnn.py:367; training re-folds every step because the weights move):
+ *   scale = bn_w * rsqrt(var + eps);  shift = bn_b - mean * scale;  wf[co][...] = w[co][...] * scale[co]
+ * -- the same operations in the same order as the tensor expressions, so bit-identical to them.  Host arrays of n device
+ * pointers / sizes; w[k] is Co[k] x inner[k] dense with the output channel outermost (contiguous or channels-last weights);
+ * wf[k] has w[k]'s element order; scale[k], shift[k]: Co[k] floats.  dib_scale_rows_multi is the backward of the weight
+ * product: dw[k][co][...] = g[k][co][...] * scale[k][co]. */
+int dib_fold_bn_multi(const float *const *w, const float *const *bn_w, const float *const *bn_b, const float *const *mean,
+                      const float *const *var, const int *Co, const int *inner, int n, float eps, float *const *wf,
+                      float *const *scale, float *const *shift, void *stream);
+int dib_scale_rows_multi(const float *const *g, const float *const *scale, const int *Co, const int *inner, int n,
+                         float *const *dw, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Post-blur corruption chain of manual_blur (reference models/blur_functions.py:72-81) in one pass:

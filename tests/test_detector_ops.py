@@ -113,6 +113,68 @@ def test_fixed_size_sampler_follows_the_sampling_rule():
     assert chosen.min() > 40 and chosen.max() < 140        # expectation 200 * 128 / 300 = 85
 
 
+def _ragged_targets(seed, counts, H=200, W=300, device="cpu"):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for n in counts:
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([W - 40.0, H - 40.0])
+        wh = 8 + torch.rand(n, 2, generator=g) * torch.tensor([W / 2.0, H / 2.0])
+        boxes = torch.cat((xy, torch.minimum(xy + wh, torch.tensor([float(W), float(H)]))), dim=1)
+        out.append({"boxes": boxes.to(device), "labels": torch.randint(1, 91, (n,), generator=g).to(device)})
+    return out
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_batched_rpn_assignment_equals_the_per_image_loop(device):
+    """Anchor labelling + matched boxes for every image in one set of tensor ops (ground truth padded to the longest list)
+    against the per-image loop it replaces: ragged lists, an image without any box, duplicate boxes (ties), low-quality
+    matches -- identical labels and matched boxes."""
+    from detectinblur_amd.models.faster_rcnn import fasterrcnn_resnet50_fpn
+    torch.manual_seed(0)
+    rpn = fasterrcnn_resnet50_fpn(pretrained=False, pretrained_backbone=False, num_classes=91).rpn
+    g = torch.Generator().manual_seed(4)
+    cx, cy = torch.rand(4000, generator=g) * 300, torch.rand(4000, generator=g) * 200
+    w, h = 4 + torch.rand(4000, generator=g) * 150, 4 + torch.rand(4000, generator=g) * 120
+    anchors = torch.stack((cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2), 1).to(device)
+    targets = _ragged_targets(9, [5, 0, 1, 12, 3], device=device)
+    targets[3]["boxes"][7] = targets[3]["boxes"][2]                      # a duplicate: two ground truths tie everywhere
+    targets[0]["boxes"][0] = anchors[17]                                  # an exact hit (IoU 1)
+    lab, matched = rpn.assign_targets([anchors] * 5, targets)
+    lab2, matched2 = rpn.assign_targets_per_image([anchors] * 5, targets)
+    assert lab.shape == (5, 4000) and matched.shape == (5, 4000, 4)
+    assert torch.equal(lab, lab2) and torch.equal(matched, matched2)
+    assert set(lab.unique().tolist()) == {-1.0, 0.0, 1.0} and float(lab[1].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_batched_roi_sampling_equals_the_per_image_loop(device):
+    """RoI sampling for every image at once against the per-image loop: same candidates, labels, sampled RoIs, regression
+    targets and validity flags for the same generator state (ragged ground truth, an image without boxes, short proposal lists)."""
+    from detectinblur_amd.models.faster_rcnn import fasterrcnn_resnet50_fpn
+    torch.manual_seed(0)
+    heads = fasterrcnn_resnet50_fpn(pretrained=False, pretrained_backbone=False, num_classes=91, box_batch_size_per_image=64).roi_heads
+    targets = _ragged_targets(11, [4, 0, 9, 1], device=device)
+    g = torch.Generator().manual_seed(5)
+    xy = torch.rand(4, 300, 2, generator=g) * torch.tensor([250.0, 160.0])
+    wh = 5 + torch.rand(4, 300, 2, generator=g) * torch.tensor([140.0, 100.0])
+    boxes = torch.cat((xy, xy + wh), dim=2).to(device)
+    boxes[0, :4] = targets[0]["boxes"] + 1.5                              # some proposals close to ground truth
+    boxes[2, :9] = targets[2]["boxes"] - 2.0
+    ok = (torch.arange(300)[None, :] < torch.tensor([300, 300, 280, 20])[:, None]).to(device)
+    out = {}
+    for flag in (True, False):
+        heads.batched = flag
+        torch.manual_seed(21)
+        if device == "cuda":
+            torch.cuda.manual_seed(21)
+        out[flag] = heads.select_training_samples((boxes.clone(), ok.clone()), [dict(t) for t in targets])
+    heads.batched = True
+    (ra, la, ta, oa), (rb, lb, tb, ob) = out[True], out[False]
+    assert all(torch.equal(x, y) for x, y in zip(ra, rb)) and torch.equal(la, lb) and torch.equal(oa, ob)
+    assert torch.allclose(ta, tb, rtol=0, atol=0, equal_nan=True)
+    assert int((la > 0).sum()) > 0 and int((la == 0).sum()) > 0
+
+
 def test_masked_fastrcnn_loss_equals_the_ragged_form():
     from detectinblur_amd.models.roi_heads import fastrcnn_loss
     torch.manual_seed(1)
@@ -696,3 +758,61 @@ def test_stem_bias_relu_maxpool_in_one_pass_equals_the_three_torch_ops():
     finally:
         B.FUSE_STEM_POOL = True
     assert torch.equal(fused, plain)
+
+
+@pytest.mark.gpu
+def test_fold_all_equals_the_per_convolution_folds_bit_for_bit():
+    """All frozen batch-norm folds of the ResNet body in one launch per 32 (dib_fold_bn_multi) against the tensor expressions
+    they replace -- scale = w_bn * rsqrt(var + eps), shift = b_bn - mean * scale, w * scale[co] -- forward (folded weights and
+    shifts of all 53 pairs, contiguous and channels-last weights, the 7x7 stem with 147 elements per channel) and backward
+    (dw = g * scale[co]): equal bit for bit.  Frozen pairs are left to the inference cache; the parked results are gone after
+    the forward pass."""
+    from detectinblur_amd.models import backbone as B
+    torch.manual_seed(3)
+    body = B.ResNet50Body().cuda()
+    body.layer2.to(memory_format=torch.channels_last)
+    for p in body.layer1.parameters():
+        p.requires_grad_(False)
+    for mod in body.modules():
+        if isinstance(mod, B.FrozenBatchNorm2d):
+            mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-.2, .2); mod.running_mean.uniform_(-.2, .2); mod.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(1, 3, 64, 64, device="cuda")
+    pairs = B._begin_step_folds(body, x)
+    try:
+        assert pairs is not None and len(pairs) == 53 - 10                          # layer1 (3 blocks x 3 + downsample) is frozen
+        parked = [conv.__dict__["_dib_step_fold"] for conv, _ in pairs]
+        g = [torch.randn_like(w) for w, _ in parked]
+        torch.autograd.backward([w for w, _ in parked], g)
+        got_dw = [conv.weight.grad.clone() for conv, _ in pairs]
+        for (conv, bn), (wf, shift) in zip(pairs, parked):
+            conv.weight.grad = None
+            scale, want_shift = bn.affine()
+            want = conv.weight * scale.reshape(-1, 1, 1, 1)
+            assert torch.equal(wf, want) and wf.stride() == want.stride(), conv
+            assert torch.equal(shift, want_shift) and not shift.requires_grad
+        for (conv, bn), gi in zip(pairs, g):
+            (conv.weight * bn.affine()[0].reshape(-1, 1, 1, 1)).backward(gi)
+        for (conv, _), dw in zip(pairs, got_dw):
+            assert torch.equal(conv.weight.grad, dw)
+        assert "_dib_step_fold" not in body.layer1[0].conv1.__dict__
+    finally:
+        B._end_step_folds(pairs)
+    assert all("_dib_step_fold" not in conv.__dict__ for conv, _ in pairs)
+    # through the module: the parked folds are used and cleaned up, the result equals the per-convolution path
+    for p in body.parameters():
+        p.grad = None
+    img = torch.randn(2, 3, 96, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = {}
+    try:
+        for flag in (True, False):
+            B.FOLD_ALL = flag
+            body.zero_grad()
+            feats = body(img)
+            assert all("_dib_step_fold" not in conv.__dict__ for conv, _ in pairs)
+            sum((f * f).mean() for f in feats).backward()
+            res[flag] = ([f.detach().clone() for f in feats], body.layer4[2].conv3.weight.grad.clone())
+    finally:
+        B.FOLD_ALL = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm())                      # same folded weights; MIOpen's own run-to-run noise
+    assert float((res[True][1] - res[False][1]).norm()) <= 1e-4 * float(res[False][1].norm())
