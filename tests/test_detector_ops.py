@@ -816,3 +816,4 @@ def test_fold_all_equals_the_per_convolution_folds_bit_for_bit():
     for a, b in zip(res[True][0], res[False][0]):
         assert float((a - b).norm()) <= 1e-5 * float(b.norm())                      # same folded weights; MIOpen's own run-to-run noise
     assert float((res[True][1] - res[False][1]).norm()) <= 1e-4 * float(res[False][1].norm())
+
