@@ -14,9 +14,28 @@ import os as _os
 # MIOpen picks each convolution's kernel by timing every applicable solver the first time it sees a
 # shape (~90 s for this detector at b=8 x 800x1344 on a fresh machine) and remembers the result in a
 # "user find-db".  `miopen_db/` ships that database for the BASELINE shapes on gfx950, so a fresh
-# process warms up in about a second; unknown shapes are tuned as usual and appended.  Respect an
-# explicit MIOPEN_USER_DB_PATH; DIB_NO_MIOPEN_DB=1 opts out.  Must run before the first convolution.
-if not _os.environ.get("DIB_NO_MIOPEN_DB"):
+# process warms up in about a second.  The process works on a PRIVATE COPY of it (a temporary directory):
+# MIOpen appends what it learns about new shapes to the user db, and a later process that read those
+# records chose other kernels than the process that wrote them -- the same `evaluate.main` command gave
+# different last bits from one run to the next (tests/test_full_size_gpu.py), and a process that ran in
+# MIOpen's deterministic mode left records that made every later process 50x slower
+# (profiles/r4_nondeterminism.txt).  From a private copy every process starts from the same state.
+# Respect an explicit MIOPEN_USER_DB_PATH; DIB_NO_MIOPEN_DB=1 opts out; DIB_MIOPEN_DB_INPLACE=1 works on
+# the shipped directory itself (scratch/tune_eval_db.py: to extend the shipped db).  Must run before the
+# first convolution.
+if not _os.environ.get("DIB_NO_MIOPEN_DB") and "MIOPEN_USER_DB_PATH" not in _os.environ:
     _db = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
-    if _os.path.isdir(_db) and _os.access(_db, _os.W_OK):
-        _os.environ.setdefault("MIOPEN_USER_DB_PATH", _db)
+    if _os.path.isdir(_db):
+        if _os.environ.get("DIB_MIOPEN_DB_INPLACE"):
+            if _os.access(_db, _os.W_OK):
+                _os.environ["MIOPEN_USER_DB_PATH"] = _db
+        else:
+            import atexit as _atexit
+            import shutil as _shutil
+            import tempfile as _tempfile
+            _tmp = _tempfile.mkdtemp(prefix="dib_miopen_db_")
+            for _f in _os.listdir(_db):
+                if _os.path.isfile(_os.path.join(_db, _f)):
+                    _shutil.copy(_os.path.join(_db, _f), _tmp)
+            _os.environ["MIOPEN_USER_DB_PATH"] = _tmp
+            _atexit.register(_shutil.rmtree, _tmp, True)

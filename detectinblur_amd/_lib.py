@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 DIB_F16, DIB_F32 = 0, 1
 DIB_ACC_BITEXACT, DIB_ACC_FP32, DIB_ACC_FMA16 = 0, 1, 2
 DIB_EINVAL, DIB_ESHAPE, DIB_EHIP, DIB_ENOT128, DIB_ECAPTURE = -1, -2, -3, -4, -5
-DIB_STEP_PSFS_COMPLETE = 1
+DIB_STEP_PSFS_COMPLETE, DIB_STEP_LARGE_WINDOW = 1, 2
+DIB_COMPACT_LARGE_WINDOW, DIB_WINDOW_LARGE = 8, 0x100
 
 _lib = None
 

@@ -40,8 +40,9 @@ def table_words(K):
 class TapTables:
     """Device-resident tap tables for a batch of PSFs (see include/dib.h, `Tap tables`)."""
 
-    def __init__(self, K, count, device):
+    def __init__(self, K, count, device, large=False):
         self.K, self.count = K, count
+        self.large = bool(large)      # compacted for the large LDS window (include/dib.h: DIB_COMPACT_LARGE_WINDOW): the blur must be told
         self.words = table_words(K)
         if self.words == 0:
             raise ValueError("PSF must be 128 or 256 wide, got %d" % K)
@@ -78,10 +79,38 @@ class TapTables:
         return (rc >> 8) & 0xff, rc & 0xff, t[:, 1]
 
 
-def compact_psfs(psfs, normalize):
+def large_window_pays(blur_dicts, n_images):
+    """Scheduling rule (never needed for correctness: both geometries give the same bits): compact for and blur with the
+    LARGE LDS window (21 x 64 segments, 4 workgroups per CU) when the launch is small -- at most LARGE_WINDOW_MAX_IMAGES
+    images, i.e. most of the chip's workgroup slots stay empty whatever is done -- and the refills saved outweigh the larger
+    ones paid.  Measured at batch 1 on 3 x 800 x 1333 (scratch/t_large_window.py, profiles/r4_large_window.txt): a standard
+    refill costs ~2.4 us, a large one ~5 us, and the large kernel ~3 us more per launch: a 16 x 48 full-exposure PSF is 19
+    standard segments (two per row: segments are runs of row-major consecutive taps) and ONE large one, 79 -> 37 us; an
+    85 x 48 PSF is 7 against 5, and stays on the standard window (51 against 63 us).  Needs the `psf_segments` hint
+    BlurImage writes (transforms.count_tap_segments); without it the standard window is used."""
+    if n_images > LARGE_WINDOW_MAX_IMAGES:
+        return False
+    std = large = 0
+    for bd in blur_dicts:
+        seg = bd.get("psf_segments") if bd.get("blurring") else None
+        if seg is None:
+            if bd.get("blurring"):
+                return False
+            continue
+        std += seg[0]
+        large += seg[1]
+    return std > 0 and 2.4 * std > 5.0 * large + 6.0
+
+
+LARGE_WINDOW_MAX_IMAGES = 2
+
+
+def compact_psfs(psfs, normalize, large_window=False):
     """psfs: list of K x K tensors (same K, same dtype) or one [B,K,K] tensor -> TapTables.
-    A list is passed as device pointers (no stacking copy)."""
+    A list is passed as device pointers (no stacking copy).  `large_window`: segment the taps for the large LDS window of
+    the default fp16 tiles (TapTables.large; sparse_blur then runs the large-window kernel)."""
     l = _lib.lib()
+    flags = int(bool(normalize)) | (_lib.DIB_COMPACT_LARGE_WINDOW if large_window else 0)
     if isinstance(psfs, (list, tuple)):
         first = psfs[0]
         _require_cuda(first, "PSF")
@@ -102,9 +131,9 @@ def compact_psfs(psfs, normalize):
                 a = p.data_ptr()
             keep.append(p)
             ptrs.append(a)
-        tabs = TapTables(K, len(keep), first.device)
+        tabs = TapTables(K, len(keep), first.device, large_window)
         tabs._pin = keep   # alive until the tables die
-        _lib.check(l.dib_psf_compact_list(_lib.ptr_array(ptrs), _DT[dt], len(keep), K, int(bool(normalize)),
+        _lib.check(l.dib_psf_compact_list(_lib.ptr_array(ptrs), _DT[dt], len(keep), K, flags,
                                           tabs.buf.data_ptr(), _stream(first.device)))
         return tabs
     stack = psfs
@@ -115,8 +144,8 @@ def compact_psfs(psfs, normalize):
     if stack.dtype not in _DT:
         raise TypeError("PSF dtype %s not supported (float16 / float32)" % stack.dtype)
     B, K = stack.shape[0], stack.shape[1]
-    tabs = TapTables(K, B, stack.device)
-    _lib.check(l.dib_psf_compact(stack.data_ptr(), _DT[stack.dtype], B, K, int(bool(normalize)),
+    tabs = TapTables(K, B, stack.device, large_window)
+    _lib.check(l.dib_psf_compact(stack.data_ptr(), _DT[stack.dtype], B, K, flags,
                                  tabs.buf.data_ptr(), _stream()))
     return tabs
 
@@ -186,6 +215,8 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
         return list(images)
     outs, ins_p, outs_p, Cs, Hs, Ws, dt, dev, _keep = d
     _await(tables)
+    if tables.large:
+        acc_mode |= _lib.DIB_WINDOW_LARGE          # the tables hold the large window's segments and offsets
     _lib.check(_lib.lib().dib_sparse_blur(_lib.ptr_array(ins_p), _lib.ptr_array(outs_p), _lib.int_array(Cs),
                                           _lib.int_array(Hs), _lib.int_array(Ws), _lib.int_array(table_index),
                                           len(images), _DT[dt], tables.buf.data_ptr(), tables.count, tables.K, acc_mode,
@@ -193,7 +224,7 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
     return outs
 
 
-def blur_step(images, table_index, psfs, normalize=True, acc_mode=_lib.DIB_ACC_BITEXACT, psfs_complete=False):
+def blur_step(images, table_index, psfs, normalize=True, acc_mode=_lib.DIB_ACC_BITEXACT, psfs_complete=False, large_window=False):
     """compact_psfs(psfs) + sparse_blur(images, table_index, tables) behind ONE library call (dib_blur_step), the tables
     in library-owned buffers (two per stream, alternating).  psfs: list of K x K CUDA tensors of one dtype, 16-byte
     aligned and contiguous (anything else is copied first).  `psfs_complete`: the caller states that the PSF buffers are
@@ -229,10 +260,13 @@ def blur_step(images, table_index, psfs, normalize=True, acc_mode=_lib.DIB_ACC_B
     l = _lib.lib()
     args = (_lib.ptr_array(ptrs), _DT[pdt], len(ptrs), K, int(bool(normalize)), _lib.ptr_array(ins_p), _lib.ptr_array(outs_p),
             _lib.int_array(Cs), _lib.int_array(Hs), _lib.int_array(Ws), _lib.int_array(table_index), len(images), _DT[dt], acc_mode)
-    rc = l.dib_blur_step(*args, None, _lib.DIB_STEP_PSFS_COMPLETE if psfs_complete else 0, _stream(dev))
+    if large_window and (dt != torch.float16 or acc_mode == _lib.DIB_ACC_FP32):
+        large_window = False                # the large window serves the default fp16 tiles only
+    lw = _lib.DIB_STEP_LARGE_WINDOW if large_window else 0
+    rc = l.dib_blur_step(*args, None, (_lib.DIB_STEP_PSFS_COMPLETE if psfs_complete else 0) | lw, _stream(dev))
     if rc == _lib.DIB_ECAPTURE:            # the current stream is being captured: tables from the capture's pool
-        tabs = TapTables(K, len(ptrs), dev)
-        rc = l.dib_blur_step(*args, tabs.buf.data_ptr(), 0, _stream(dev))
+        tabs = TapTables(K, len(ptrs), dev, large_window)
+        rc = l.dib_blur_step(*args, tabs.buf.data_ptr(), lw, _stream(dev))
     _lib.check(rc)
     return outs
 
@@ -255,7 +289,7 @@ def side_stream(device):
     return _side_streams[idx]
 
 
-def compact_psfs_ahead(psfs, normalize, after_current=True):
+def compact_psfs_ahead(psfs, normalize, after_current=True, large_window=False):
     """compact_psfs on the device's side stream.  `after_current`: the side stream first waits for the work already
     queued on the current stream (needed when that work PRODUCES the PSFs, e.g. their host-to-device copy was issued
     on it); pass False when the PSFs are known to be complete (bench.py's resident PSFs), so that the compaction may
@@ -267,7 +301,7 @@ def compact_psfs_ahead(psfs, normalize, after_current=True):
     if after_current:
         side.wait_stream(main)
     with torch.cuda.stream(side):
-        tabs = compact_psfs(psfs, normalize)
+        tabs = compact_psfs(psfs, normalize, large_window)
         tabs.ready = torch.cuda.Event()
         tabs.ready.record(side)
     # the PSFs were allocated on the main stream and are read on the side stream: tell the caching allocator, or a

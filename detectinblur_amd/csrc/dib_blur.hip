@@ -478,6 +478,17 @@ constexpr int QPITCH = QUAD_PITCH * 8;        // bytes per LDS row (448)
 constexpr int QLDS_BYTES = LROWS * QPITCH;    // 19,712 B
 static_assert(QPITCH == 448, "the asm below hard-codes the LDS row pitch");
 static_assert(LROWS % NW == 0, "every wave fills the same number of window rows");
+// The two window geometries of the quad shape (dib_common.h): L = false the standard one above, L = true the LARGE one
+// (21 x 64 segments, 52 rows x 96 elements = 39,936 B, 4 workgroups per CU) for launches that leave the chip's slots empty.
+template <bool L> struct QGeom {
+  static constexpr int PITCH_EL = L ? QUAD_PITCH_L : QUAD_PITCH;   // elements per LDS row
+  static constexpr int PITCH = PITCH_EL * 8;                       // bytes per LDS row
+  static constexpr int ROWS = TH + (L ? SEG_ROWS_L : SEG_ROWS);    // LDS rows
+  static constexpr int GQ = ROWS / NW;                             // rows a wave fills
+  static constexpr int BYTES = ROWS * PITCH;
+};
+static_assert(QGeom<false>::PITCH == QPITCH && QGeom<false>::ROWS == LROWS && QGeom<false>::BYTES == QLDS_BYTES, "standard geometry");
+static_assert(QGeom<true>::PITCH == 768 && QGeom<true>::ROWS % NW == 0 && QGeom<true>::BYTES == 39936, "the asm below hard-codes the large window's row pitch");
 
 // Tap loop of the quad shape: 4 x 8-byte reads per tap, rows i = 0..3 land in v[base+2i : base+2i+1] = the operands of
 // accumulators 2i (columns j, j+32) and 2i+1 (columns j+64, j+96); the LDS address is one v_mad_u32_u16 (low 16 bits of
@@ -516,13 +527,21 @@ static_assert(LROWS % NW == 0, "every wave fills the same number of window rows"
   "v_mad_u32_u16 v48, " OFF ", 1, %11\n\t"                                                                    \
   "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+2], v48 offset:448\n\t"                            \
   "ds_read_b32 v[" #base "+4], v48 offset:896\n\tds_read_b32 v[" #base "+6], v48 offset:1344\n\t"
+#define DIBQ_READ_L(base, OFF)                                                                               \
+  "v_mad_u32_u16 v48, " OFF ", 1, %11\n\t"                                                                    \
+  "ds_read_b64 v[" #base ":" #base "+1], v48\n\tds_read_b64 v[" #base "+2:" #base "+3], v48 offset:768\n\t"    \
+  "ds_read_b64 v[" #base "+4:" #base "+5], v48 offset:1536\n\tds_read_b64 v[" #base "+6:" #base "+7], v48 offset:2304\n\t"
+#define DIBQ_READH_L(base, OFF)                                                                              \
+  "v_mad_u32_u16 v48, " OFF ", 1, %11\n\t"                                                                    \
+  "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+2], v48 offset:768\n\t"                            \
+  "ds_read_b32 v[" #base "+4], v48 offset:1536\n\tds_read_b32 v[" #base "+6], v48 offset:2304\n\t"
 #define DIBQ_MADDH_X(W) DIBQ_MUL(32, W) DIBQ_MUL(34, W) DIBQ_MUL(36, W) DIBQ_MUL(38, W) DIBQ_ADD(32, 0) DIBQ_ADD(34, 2) DIBQ_ADD(36, 4) DIBQ_ADD(38, 6)
 #define DIBQ_MADDH_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(42, W) DIBQ_MUL(44, W) DIBQ_MUL(46, W) DIBQ_ADD(40, 0) DIBQ_ADD(42, 2) DIBQ_ADD(44, 4) DIBQ_ADD(46, 6)
 #define DIBQ_FMADDH_X(W) DIBQ_FMA(32, 0, W) DIBQ_FMA(34, 2, W) DIBQ_FMA(36, 4, W) DIBQ_FMA(38, 6, W)
 #define DIBQ_FMADDH_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(42, 2, W) DIBQ_FMA(44, 4, W) DIBQ_FMA(46, 6, W)
 #define DIBQ_LOAD(PAIR) "s_load_dwordx2 " PAIR ", %10, %8\n\ts_add_u32 %8, %8, 8\n\t"
 #define DIBQ_NEXT(LABEL) "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 " LABEL "\n\t"
-template <bool FUSED, bool HALF>
+template <bool FUSED, bool HALF, bool L = false>
 __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
   unsigned a[8];
@@ -545,7 +564,11 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
       : "s"(ltaps), "v"(lane_addr) \
       : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", \
         "s36", "s37", "s38", "s39", "s40", "s41", "scc", "memory")
-  if constexpr (FUSED && HALF) { DIB_RQ_ASM(DIBQ_READH, DIBQ_FMADDH_X, DIBQ_FMADDH_Y); }
+  if constexpr (L && FUSED && HALF) { DIB_RQ_ASM(DIBQ_READH_L, DIBQ_FMADDH_X, DIBQ_FMADDH_Y); }
+  else if constexpr (L && FUSED) { DIB_RQ_ASM(DIBQ_READ_L, DIBQ_FMADD_X, DIBQ_FMADD_Y); }
+  else if constexpr (L && HALF) { DIB_RQ_ASM(DIBQ_READH_L, DIBQ_MADDH_X, DIBQ_MADDH_Y); }
+  else if constexpr (L) { DIB_RQ_ASM(DIBQ_READ_L, DIBQ_MADD_X, DIBQ_MADD_Y); }
+  else if constexpr (FUSED && HALF) { DIB_RQ_ASM(DIBQ_READH, DIBQ_FMADDH_X, DIBQ_FMADDH_Y); }
   else if constexpr (FUSED) { DIB_RQ_ASM(DIBQ_READ, DIBQ_FMADD_X, DIBQ_FMADD_Y); }
   else if constexpr (HALF) { DIB_RQ_ASM(DIBQ_READH, DIBQ_MADDH_X, DIBQ_MADDH_Y); }
   else { DIB_RQ_ASM(DIBQ_READ, DIBQ_MADD_X, DIBQ_MADD_Y); }
@@ -554,11 +577,12 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
 }
 
-template <int ACC>
+template <int ACC, bool L = false>
 __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
                                                    unsigned *lds) {
 #pragma clang fp contract(off)
-  constexpr int GQ = LROWS / NW;              // LDS rows a wave fills (11)
+  constexpr int GQ = QGeom<L>::GQ;            // LDS rows a wave fills (11; large window: 15)
+  constexpr int QPITCH = QGeom<L>::PITCH, QUAD_PITCH = QGeom<L>::PITCH_EL, LROWS = QGeom<L>::ROWS;   // shadow the standard geometry's constants
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int H = d.H, W = d.W, w2 = W * 2;
   const int mode = pad_mode_for(K, H, W);
@@ -596,20 +620,22 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     if (sg > 0) seg = segs[sg];
     const Window w = window_of(seg);
     const int lane = fresh_lane();
-    // ---- fill: per LDS row the four values P[lane + 32 m] of element `lane` ----------------------------------------
-    short v[GQ][4];
-    unsigned coff[4];
+    // ---- fill: per LDS row the four values P[lane + 32 m] of element `lane` (large window: six values -- element 64 + lane,
+    // owned by lanes 0-31, is {P[lane + 64], P[lane + 96], P[lane + 128], P[lane + 160]}, the first two shared with element lane)
+    constexpr int NK = L ? 6 : 4;
+    short v[GQ][NK];
+    unsigned coff[NK];
     int soff[GQ];
     unsigned zmask = 0;
     const int c_first = x0 + pb - w.cmax, r_first = y0 + pb - w.rl;
     const bool zero_mode = mode == PAD_ZERO;
-    if (!zero_mode && c_first >= 0 && c_first + 63 + 96 <= W - 1) {
+    if (!zero_mode && c_first >= 0 && c_first + 63 + 32 * (NK - 1) <= W - 1) {
       const unsigned c0 = 2u * (unsigned)(c_first + lane);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) coff[k] = c0 + 64u * k;
+      for (int k = 0; k < NK; ++k) coff[k] = c0 + 64u * k;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NK; ++k) {
         bool z;
         coff[k] = 2u * (unsigned)map_coord_sel(c_first + lane + 32 * k, W, pa, pb, mode, z);
         zmask |= z ? 1u << k : 0u;
@@ -633,7 +659,7 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     for (int g = 0; g < GQ; ++g) {
       const int so = __builtin_amdgcn_readfirstlane(soff[g]);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
+      for (int k = 0; k < NK; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
     }
     if (sg > 0) __syncthreads();  // every wave is done reading the previous window
     // Elements 0 .. 31 + column extent are read by the taps; writing all 56 of a row costs the same (an LDS store is
@@ -642,7 +668,25 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     const bool masked = __builtin_amdgcn_ballot_w64(zmask != 0) != 0;   // PAD_ZERO images only
     const int wl = fresh_lane();
     const unsigned wp = lds0 + (unsigned)(qb * QPITCH + wl * 8);
-    if (wl < QUAD_PITCH) {
+    if constexpr (L) {     // elements lane (all lanes) and 64 + lane (lanes 0-31); zero-fill flags applied per value
+#pragma unroll
+      for (int g = 0; g < GQ; ++g) {
+        unsigned u[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+          u[k] = (masked && (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u))) ? 0u : (unsigned)(unsigned short)v[g][k];
+        lds_u2v e;
+        e.x = u[0] | (u[1] << 16);
+        e.y = u[2] | (u[3] << 16);
+        *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
+        if (wl < 32) {
+          lds_u2v f;
+          f.x = u[2] | (u[3] << 16);
+          f.y = u[4] | (u[5] << 16);
+          *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH + 512)) = f;
+        }
+      }
+    } else if (wl < QUAD_PITCH) {
       if (!masked) {
 #pragma unroll
         for (int g = 0; g < GQ; ++g) {
@@ -669,8 +713,8 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     __syncthreads();
     const int tl = fresh_lane();
     const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
-    if (W - x0 <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true>(acc, ltaps, w.t0, w.n, lane_addr);
-    else tap_loop_quad<ACC == DIB_ACC_FMA16, false>(acc, ltaps, w.t0, w.n, lane_addr);
+    if (W - x0 <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true, L>(acc, ltaps, w.t0, w.n, lane_addr);
+    else tap_loop_quad<ACC == DIB_ACC_FMA16, false, L>(acc, ltaps, w.t0, w.n, lane_addr);
   }
   // ---- store: a store instruction writes 32 columns of row y (lanes 0-31) and of row y + 4 (lanes 32-63); lanes
   // outside the image get an out-of-range buffer offset and are dropped by the range check ----------------------------
@@ -759,6 +803,22 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch) 
     }
   }
 #endif
+}
+
+// The same tile function on the LARGE window (39.9 KB of LDS: 4 workgroups per CU, so up to 128 registers per lane cost
+// nothing; the fill keeps 78 window values in flight instead of 44).
+template <int ACC, int KC>
+__global__ __launch_bounds__(256, 4) void blur_quad_large_f16_kernel(BlurBatch batch) {
+  constexpr int K = KC;
+  extern __shared__ unsigned nlds[];
+  const ImageDesc d = batch.img[blockIdx.y];
+  const int per_ch = d.tiles_x * d.tiles_y;
+  int local;
+  if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
+  const int ch = magic_div(local, d.inv_per_ch);
+  local -= ch * per_ch;
+  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
+  blur_quad_tile_f16<ACC, true>(d, d.tab, K, ch, tx, ty, nlds);
 }
 
 template <int ACC>
@@ -887,6 +947,10 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 256>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_large_f16_kernel<DIB_ACC_BITEXACT, 128>), QGeom<true>::BYTES));
+    DIB_HIP_CHECK(opt_in((blur_quad_large_f16_kernel<DIB_ACC_FMA16, 128>), QGeom<true>::BYTES));
+    DIB_HIP_CHECK(opt_in((blur_quad_large_f16_kernel<DIB_ACC_BITEXACT, 256>), QGeom<true>::BYTES));
+    DIB_HIP_CHECK(opt_in((blur_quad_large_f16_kernel<DIB_ACC_FMA16, 256>), QGeom<true>::BYTES));
     st.ready = true;
   }
   return DIB_OK;
@@ -902,6 +966,12 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   }
   if (K != 128 && K != 256) { set_error("dib_sparse_blur: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
   if (dtype != DIB_F16 && dtype != DIB_F32) { set_error("dib_sparse_blur: unknown dtype %d", dtype); return DIB_EINVAL; }
+  const bool large = (acc_mode & DIB_WINDOW_LARGE) != 0;      // the tables were compacted with DIB_COMPACT_LARGE_WINDOW
+  acc_mode &= ~DIB_WINDOW_LARGE;
+  if (large && (dtype != DIB_F16 || acc_mode == DIB_ACC_FP32 || g_shape != 0)) {
+    set_error("dib_sparse_blur: DIB_WINDOW_LARGE serves fp16 images in DIB_ACC_BITEXACT / DIB_ACC_FMA16 on the default tile shape only");
+    return DIB_EINVAL;
+  }
   if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FP32 && acc_mode != DIB_ACC_FMA16) { set_error("dib_sparse_blur: unknown accumulation mode %d", acc_mode); return DIB_EINVAL; }
   if (acc_mode != DIB_ACC_BITEXACT && dtype != DIB_F16) { set_error("dib_sparse_blur: DIB_ACC_FP32 / DIB_ACC_FMA16 apply to fp16 images only (fp32 images already accumulate in fp32)"); return DIB_EINVAL; }
   for (int i = 0; i < B; ++i) {
@@ -978,7 +1048,9 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       const dim3 grid(gx, tiled.n);
 #define DIB_LAUNCH_QUAD(ACCM)                                                                                             \
   do {                                                                                                                   \
-    if (K == 128) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled); \
+    if (large && K == 128) hipLaunchKernelGGL((blur_quad_large_f16_kernel<ACCM, 128>), grid, dim3(256), QGeom<true>::BYTES, s, tiled); \
+    else if (large) hipLaunchKernelGGL((blur_quad_large_f16_kernel<ACCM, 256>), grid, dim3(256), QGeom<true>::BYTES, s, tiled);       \
+    else if (K == 128) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled); \
     else hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 256>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled);          \
   } while (0)
       if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_QUAD(DIB_ACC_FMA16);

@@ -24,6 +24,16 @@ constexpr int SEG_ROWS = 12, SEG_COLS = 24;
 constexpr int WIN_PITCH = 96;              // 8-byte words per LDS window row (64 + SEG_COLS are used)
 constexpr int QUAD_PITCH = 32 + SEG_COLS;  // 8-byte elements {P[k], P[k+32], P[k+64], P[k+96]} per LDS window row (56)
 static_assert(WIN_PITCH >= 64 + SEG_COLS, "window row too short for a segment");
+// The LARGE window of the default ("quad") tiles: segments of up to 21 rows x 64 columns, 52 LDS rows of 96 elements = 39,936 B
+// (4 workgroups per CU instead of 8).  For launches that leave most of the chip's slots empty anyway (evaluation at batch 1:
+// 825 workgroups on 2,048 slots) and whose PSF is wide or tall.  Segments are runs of ROW-MAJOR consecutive taps (the order
+// the reference accumulates in), so a run can only cross a row boundary when whole rows fit the window's columns: a
+// full-exposure PSF 48 columns wide is 19 standard segments (two per row) and ONE large one; every segment is a window refill
+// (~3 us at batch 1) that nothing overlaps.  A table is compacted for ONE geometry (tab[HDR_K] = K | geometry << 16); the blur
+// is told which by its caller.
+constexpr int SEG_ROWS_L = 20, SEG_COLS_L = 63, QUAD_PITCH_L = 32 + SEG_COLS_L + 1;   // 96 elements per LDS row
+static_assert(QUAD_PITCH_L == 96, "the large window's fill writes elements lane and 64 + lane");
+constexpr int COMPACT_NORMALIZE = 1, COMPACT_NO_SEGMENTS = 4, COMPACT_LARGE_WINDOW = 8;   // flag bits of the compaction kernel
 
 __host__ __device__ inline int table_rowptr_off() { return HDR_WORDS; }
 __host__ __device__ inline int table_taps_off(int K) { return (HDR_WORDS + K + 1 + 3) & ~3; }

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
           tab[HDR_NTAPS] = n_raw;
           tab[HDR_RMIN] = n_raw ? (s_rc[0] >> 8) : K; tab[HDR_RMAX] = n_raw ? (s_rc[n_raw - 1] >> 8) : -1;
           tab[HDR_CMIN] = cmn; tab[HDR_CMAX] = cmx;
-          tab[HDR_K] = K; tab[HDR_SUM] = (int)E::bits(total);
+          tab[HDR_K] = K | ((normalize & COMPACT_LARGE_WINDOW) ? 1 << 16 : 0); tab[HDR_SUM] = (int)E::bits(total);
         }
       }
       ntaps = n_raw;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
     tab[table_rowptr_off() + K] = ntaps;
     tab[HDR_NTAPS] = ntaps;
     tab[HDR_RMIN] = s_ext[0]; tab[HDR_RMAX] = s_ext[1]; tab[HDR_CMIN] = s_ext[2]; tab[HDR_CMAX] = s_ext[3];
-    tab[HDR_K] = K; tab[HDR_SUM] = (int)E::bits(total);
+    tab[HDR_K] = K | ((normalize & COMPACT_LARGE_WINDOW) ? 1 << 16 : 0); tab[HDR_SUM] = (int)E::bits(total);
   }
   if (__builtin_amdgcn_ballot_w64(mask != 0) != 0)
 #pragma unroll
@@ -345,12 +345,15 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   __syncthreads();
   }  // general path
   if (wave != 0) return;
-  if (normalize & 4) return;  // diagnostics: skip the segmentation
+  if (normalize & COMPACT_NO_SEGMENTS) return;  // diagnostics: skip the segmentation
 
   // ---- segmentation (wave 0): greedy runs with row span <= SEG_ROWS and column span <= SEG_COLS --------
   uint4 *segs = reinterpret_cast<uint4 *>(tab + table_segs_off(K));
   unsigned *ltaps = reinterpret_cast<unsigned *>(tab + table_ltaps_off(K));
   unsigned *ltaps_q = reinterpret_cast<unsigned *>(tab + table_ltaps_q_off(K));
+  // segment limits and the quad window's row pitch of the geometry this table is compacted for (dib_common.h)
+  const bool large = (normalize & COMPACT_LARGE_WINDOW) != 0;
+  const int seg_rows = large ? SEG_ROWS_L : SEG_ROWS, seg_cols = large ? SEG_COLS_L : SEG_COLS, qpitch = large ? QUAD_PITCH_L : QUAD_PITCH;
   // per-tap LDS offsets of a closed segment [s0, s1) with last row rl and last column cmx
   auto emit_ltaps = [&](int s0, int s1, int rl, int cmx) {
     for (int j = s0 + lane; j < s1; j += 64) {
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
       else { const uint2 tp = taps[j]; rcj = tp.x & 0xffffu; wj = tp.y & 0xffffu; }
       const int rj = rcj >> 8, cj = rcj & 255;
       ltaps[j] = (unsigned)(((rl - rj) * WIN_PITCH + (cmx - cj)) * 8) | (wj << 16);
-      ltaps_q[j] = (unsigned)(((rl - rj) * QUAD_PITCH + (cmx - cj)) * 8) | (wj << 16);
+      ltaps_q[j] = (unsigned)(((rl - rj) * qpitch + (cmx - cj)) * 8) | (wj << 16);
     }
   };
   int nseg = 0, seg_start = 0, seg_r0 = 0, seg_rlast = 0, car_cmin = 1 << 20, car_cmax = -1;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
       int pm = wave_scan_min_i32((valid && lane >= lo) ? c : (1 << 20), lane);
       int px = wave_scan_max_i32((valid && lane >= lo) ? c : -1, lane);
       pm = min(pm, car_cmin); px = max(px, car_cmax);
-      const bool bad = valid && lane >= lo && ((r - seg_r0 > SEG_ROWS) || (px - pm > SEG_COLS));
+      const bool bad = valid && lane >= lo && ((r - seg_r0 > seg_rows) || (px - pm > seg_cols));
       const unsigned long long fail = __ballot(bad);
       const unsigned long long vmask = __ballot(valid);
       const int last_valid = 63 - __clzll((long long)vmask);  // vmask != 0 inside the loop
@@ -433,7 +436,9 @@ int dib::compact_launch(const void *const *ptrs, int dtype, int B, int K, int no
       pp.p[i] = ptrs[b0 + i];
     }
     int *t = tables + (size_t)b0 * stride;
-    const int flags = normalize ? 1 : 0;
+    // `normalize` doubles as the flag word: bit 3 (DIB_COMPACT_LARGE_WINDOW) selects the large-window segmentation, anything
+    // else that is non-zero means "divide by the sum first"
+    const int flags = ((normalize & ~DIB_COMPACT_LARGE_WINDOW) ? COMPACT_NORMALIZE : 0) | ((normalize & DIB_COMPACT_LARGE_WINDOW) ? COMPACT_LARGE_WINDOW : 0);
     if (dtype == DIB_F16 && K == 128) hipExtLaunchKernelGGL((dib::psf_compact_kernel<__half, 128>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);
     else if (dtype == DIB_F16) hipExtLaunchKernelGGL((dib::psf_compact_kernel<__half, 256>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);
     else if (K == 128) hipExtLaunchKernelGGL((dib::psf_compact_kernel<float, 128>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);

@@ -49,7 +49,11 @@ extern "C" int dib_blur_step(const void *const *psf_ptrs, int psf_dtype, int num
   if (num_psfs <= 0 || !psf_ptrs) { set_error("dib_blur_step: no PSFs"); return DIB_EINVAL; }
   if (K != 128 && K != 256) { set_error("dib_blur_step: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
   if (psf_dtype != DIB_F16 && psf_dtype != DIB_F32) { set_error("dib_blur_step: unknown PSF dtype %d", psf_dtype); return DIB_EINVAL; }
-  if (flags & ~DIB_STEP_PSFS_COMPLETE) { set_error("dib_blur_step: unknown flags 0x%x", flags); return DIB_EINVAL; }
+  if (flags & ~(DIB_STEP_PSFS_COMPLETE | DIB_STEP_LARGE_WINDOW)) { set_error("dib_blur_step: unknown flags 0x%x", flags); return DIB_EINVAL; }
+  if (flags & DIB_STEP_LARGE_WINDOW) {     // compact for and blur with the large LDS window
+    normalize = (normalize ? 1 : 0) | DIB_COMPACT_LARGE_WINDOW;
+    acc_mode |= DIB_WINDOW_LARGE;
+  }
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   DIB_HIP_CHECK(hipStreamIsCapturing(s, &cap));

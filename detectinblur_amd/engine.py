@@ -83,7 +83,9 @@ def _stage(images_CPU, targets, blur_dicts, device, blurring, want_tables, cuda)
         if want_tables and cuda and active and len({tuple(p.shape) for p in active}) == 1 and active[0].dim() == 2 \
                 and active[0].shape[0] in (128, 256):
             from . import blur_ops
-            tables = blur_ops.compact_psfs_ahead(active, normalize=True, after_current=True)
+            # fp16 images only (what the blur of this engine sees); the box growth reads the tap list, not the segments
+            large = blur_ops.large_window_pays(blur_dicts, len(active))
+            tables = blur_ops.compact_psfs_ahead(active, normalize=True, after_current=True, large_window=large)
         # theta / lambda1 / lambda2: one [3, B] pinned tensor, one copy
         scal = torch.tensor([[bd["theta_rad"] for bd in blur_dicts], [bd["scale_factor_lambda1"] for bd in blur_dicts],
                              [bd["scale_factor_lambda2"] for bd in blur_dicts]], dtype=torch.float16)

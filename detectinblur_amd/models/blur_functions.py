@@ -141,7 +141,8 @@ def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=Non
         if taps is not None:
             perm.sort(key=taps.__getitem__, reverse=True)      # stable: equal tap counts keep their order
     if tables is None:
-        outs = blur_ops.blur_step([images_GPU[idx[k]] for k in perm], perm, psfs, True, acc_mode, psfs_complete)
+        large = blur_dicts is not None and blur_ops.large_window_pays([blur_dicts[i] for i in idx], len(idx))
+        outs = blur_ops.blur_step([images_GPU[idx[k]] for k in perm], perm, psfs, True, acc_mode, psfs_complete, large)
     else:
         outs = blur_ops.sparse_blur([images_GPU[idx[k]] for k in perm], perm, tables, acc_mode)
     for j, k in enumerate(perm):

@@ -12,8 +12,9 @@ the keys it writes into `blur_dict`; what changes is where the time goes:
   * `--cpu_blur` keeps the reference's FFT path (motion_blur/blur_image.py) for comparison runs.
 
 Extra, optional keys (ignored by reference-shaped consumers): `blur_dict["psf_extent"]` =
-(rmin, rmax, cmin, cmax) of the PSF support and `blur_dict["psf_taps"]` = its non-zero count, free to
-compute here and used as scheduling hints by the GPU blur (heaviest image first).
+(rmin, rmax, cmin, cmax) of the PSF support, `blur_dict["psf_taps"]` = its non-zero count and `blur_dict["psf_segments"]` =
+the number of LDS window refills it costs the blur on the (standard, large) window geometry: free to compute here and used
+as scheduling hints by the GPU blur (heaviest image first; the large window for small launches of refill-heavy PSFs).
 """
 import copy
 import math
@@ -114,6 +115,27 @@ def psf_axis_stats(psf):
     s2 = 1 - (sigmoid(math.sqrt(lambda2) / 10) - 0.5) * 0.6
     theta = -math.atan2(lambda1 - var_x, -cov)
     return theta, s1, s2, (int(ys.min()), int(ys.max()), int(xs.min()), int(xs.max()))
+
+
+# (row span, column span) limits of a tap segment for the blur's two LDS window geometries (csrc/dib_common.h: SEG_ROWS /
+# SEG_COLS and SEG_ROWS_L / SEG_COLS_L; tests/test_blur_gpu.py checks the library's segments against the same numbers)
+STANDARD_WINDOW, LARGE_WINDOW = (12, 24), (20, 63)
+
+
+def count_tap_segments(psf, limits):
+    """How many segments the tap compaction cuts this PSF into for a window geometry: greedy runs of row-major consecutive
+    non-zeros whose rows span at most limits[0] + 1 and whose columns span at most limits[1] + 1 (csrc/dib_compact.hip).  A
+    host-side scheduling hint (a weight that underflows in the normalisation would drop out on the device)."""
+    rr, cc = np.nonzero(psf)
+    if len(rr) == 0:
+        return 0
+    n, r0, lo, hi = 1, int(rr[0]), int(cc[0]), int(cc[0])
+    for r, c in zip(rr.tolist(), cc.tolist()):
+        nlo, nhi = min(lo, c), max(hi, c)
+        if r - r0 > limits[0] or nhi - nlo > limits[1]:
+            n, r0, nlo, nhi = n + 1, r, c, c
+        lo, hi = nlo, nhi
+    return n
 
 
 def make_psf(param, fraction, center=True):
@@ -251,6 +273,7 @@ class BlurImage(object):
         blur_dict["scale_factor_lambda2"] = s2
         blur_dict["psf_extent"] = extent
         blur_dict["psf_taps"] = int(np.count_nonzero(psf))
+        blur_dict["psf_segments"] = (count_tap_segments(psf, STANDARD_WINDOW), count_tap_segments(psf, LARGE_WINDOW))
 
         if self.blur_type is not None:                                  # :418-428 nearest-type binning
             param_index = int(np.argmin(np.abs(np.asarray(PARAMS) - self.blur_type)))

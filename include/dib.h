@@ -44,6 +44,14 @@ extern "C" {
 #define DIB_ACC_FP32 1     /* fp32 accumulate, one final rounding (fp16 images only)           */
 #define DIB_ACC_FMA16 2    /* fp16 accumulate with a fused multiply-add: one rounding per tap
                               instead of two; half the arithmetic, not the reference's (fp16 only) */
+/* The LARGE LDS window of the default fp16 tiles (segments of up to 21 PSF rows x 64 columns instead of 13 x 25; 39.9 KB,
+ * four workgroups per CU instead of eight): fewer window refills for PSFs that span many columns or rows -- full-exposure
+ * trajectories at batch 1, where the grid leaves most workgroup slots empty anyway.  Same results, bit for bit.  A table is
+ * compacted for ONE geometry: pass DIB_COMPACT_LARGE_WINDOW (or-ed into `normalize`) to dib_psf_compact* and DIB_WINDOW_LARGE
+ * (or-ed into `acc_mode`) to the dib_sparse_blur calls that read those tables, DIB_STEP_LARGE_WINDOW to dib_blur_step.
+ * fp16 images with DIB_ACC_BITEXACT / DIB_ACC_FMA16 only (DIB_EINVAL otherwise). */
+#define DIB_COMPACT_LARGE_WINDOW 8
+#define DIB_WINDOW_LARGE 0x100
 
 int dib_abi_version(void);
 const char *dib_last_error(void);
@@ -60,7 +68,9 @@ const char *dib_last_error(void);
  * taps with a bounding box of at most 13 rows x 25 columns: the unit staged in LDS by the blur)
  * | ltaps[K*K+8] one word per tap: byte offset of its source word in the blur's LDS window (low
  * 16 bits) and the fp16 weight bits (high 16 bits) | ltaps_q[K*K+8] the same for the window layout
- * of the default 128-wide tiles (8-byte elements {P[k], P[k+32], P[k+64], P[k+96]}).
+ * of the default 128-wide tiles (8-byte elements {P[k], P[k+32], P[k+64], P[k+96]}).  With
+ * DIB_COMPACT_LARGE_WINDOW the segments are runs of at most 21 rows x 64 columns and ltaps_q holds the
+ * large window's offsets; word [5] carries the geometry in bit 16.
  * ------------------------------------------------------------------------------------- */
 size_t dib_tap_table_bytes(int K); /* bytes of ONE table; K is 128 or 256 */
 /* bytes of the buffer dib_psf_compact fills for B PSFs: B tables, dib_tap_table_bytes(K) apart */
@@ -113,6 +123,7 @@ int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, const int *
  * stream's table buffers: that call waits for the stream once).
  * ------------------------------------------------------------------------------------- */
 #define DIB_STEP_PSFS_COMPLETE 1
+#define DIB_STEP_LARGE_WINDOW 2 /* compact for and blur with the large LDS window (see DIB_WINDOW_LARGE) */
 int dib_blur_step(const void *const *psf_ptrs, int psf_dtype, int num_psfs, int K, int normalize,
                   const void *const *in_dev, void *const *out_dev, const int *C, const int *H, const int *W,
                   const int *table_index, int B, int dtype, int acc_mode, void *tables_dev, int flags,

@@ -119,6 +119,39 @@ def _bench_forced_dist(argv):
     return json.loads(lines[0])
 
 
+def _evaluate_main_digest(argv):
+    """`python -m detectinblur_amd.evaluate <argv>` in this (fresh) process: per sweep cell the twelve COCO statistics and a
+    SHA-256 over every detection (image id, boxes, scores, labels) and every expanded ground-truth box, bit for bit."""
+    import contextlib
+    import hashlib
+    import io
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from detectinblur_amd import evaluate
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = evaluate.main(evaluate.build_parser().parse_args(list(argv)))
+    out = {}
+    for cell in sorted(res):
+        r = res[cell]
+        h = hashlib.sha256()
+        n = 0
+        for k in sorted(r["detections"]):
+            h.update(np.int64(k).tobytes())
+            for f in ("boxes", "scores", "labels"):
+                h.update(np.ascontiguousarray(r["detections"][k][f].numpy()).tobytes())
+            h.update(np.ascontiguousarray(r["targets"][k].numpy()).tobytes())
+            n += len(r["detections"][k]["boxes"])
+        out[cell] = {"stats": [float(x) for x in r.coco_eval["bbox"].stats], "sha256": h.hexdigest(), "images": len(r["detections"]), "boxes": n}
+    lines = [l for l in buf.getvalue().splitlines() if "Average Precision" in l or "Average Recall" in l]
+    return {"cells": out, "stat_lines": lines}
+
+
+def evaluate_main_digest(out_path, argv):
+    _guarded(_evaluate_main_digest, out_path, (argv,))
+
+
 def ddp_one_rank(out_path, fused):
     _guarded(_ddp_one_rank, out_path, (fused,))
 

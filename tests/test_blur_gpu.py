@@ -523,3 +523,115 @@ def test_compaction_and_blur_are_graph_capturable():
         for outs, _ in keep:
             for a, b in zip(outs, want):
                 assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ the large LDS window (DIB_WINDOW_LARGE)
+
+def _fp16_cases():
+    return [c for c in GI.blur_cases() if np.dtype(GI.make_case_psf(c).dtype) == np.float16 or c.get("digest_only")]
+
+
+@pytest.mark.parametrize("case", GI.blur_cases(), ids=lambda c: c["name"])
+def test_large_window_kernel_against_the_reference_goldens(golden, case):
+    """The large-window build of the default kernel (segments of up to 21 rows x 64 columns, 39.9 KB of LDS) on every
+    reference golden an fp16 image takes -- all padding branches, the wrap quirk, the 256 canvas, the four 3 x 800 x 1333
+    digests (two of them full-exposure PSFs: what the geometry exists for): bit for bit."""
+    from detectinblur_amd import _lib, blur_ops
+    img = GI.make_image(case)
+    psf = GI.make_case_psf(case)
+    if img.dtype != np.float16:
+        pytest.skip("fp32 images run the generic kernel: no LDS window")
+    t_img, t_psf = _dev(img), _dev(psf)
+    if t_psf.dtype != t_img.dtype:
+        t_psf = t_psf.to(t_img.dtype)
+    tabs = blur_ops.compact_psfs([t_psf], normalize=False, large_window=True)
+    assert tabs.large and (int(tabs.buf[5].item()) >> 16) == 1 and (int(tabs.buf[5].item()) & 0xffff) == psf.shape[0]
+    out = blur_ops.sparse_blur([t_img], [0], tabs)[0].squeeze().cpu().numpy()
+    name = "blur_" + case["name"]
+    if case.get("digest_only"):
+        m = golden.meta[name]
+        assert list(out.shape) == m["shape"]
+        assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == m["sha256"]
+    else:
+        assert np.array_equal(_bits(out), golden.blur[name])
+    std = blur_ops.compact_psfs([t_psf], normalize=False)
+    assert len(tabs.segments(0)) <= len(std.segments(0))
+    # the FMA16 mode on the large window equals the FMA16 mode on the standard one
+    a = blur_ops.sparse_blur([t_img], [0], tabs, _lib.DIB_ACC_FMA16)[0]
+    b = blur_ops.sparse_blur([t_img], [0], std, _lib.DIB_ACC_FMA16)[0]
+    assert torch.equal(a, b)
+
+
+def test_large_window_segments_are_bounded_and_fewer():
+    from detectinblur_amd import blur_ops
+    rs = np.random.RandomState(78)
+    psfs = []
+    for sp, n in ((3, 20), (20, 150), (60, 600), (63, 3000)):
+        a = np.zeros((128, 128), np.float16)
+        a[np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127), np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127)] = (rs.random_sample(n) + 0.1).astype(np.float16)
+        psfs.append(a)
+    a = np.zeros((128, 128), np.float16); a[np.arange(20, 116), np.arange(20, 116)] = 0.01; psfs.append(a)      # a 96-pixel diagonal
+    a = np.zeros((128, 128), np.float16); a[:, 5] = 0.01; psfs.append(a)
+    psfs.append(np.full((128, 128), 0.001, np.float16))
+    big = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=False, large_window=True)
+    std = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=False)
+    for k, a in enumerate(psfs):
+        rr, cc = np.nonzero(a)
+        segs = big.segments(k)
+        assert segs[0][0] == 0 and segs[-1][1] == len(rr)
+        for (s0, s1, rf, rl, cmn, cmx), nxt in zip(segs, segs[1:] + [None]):
+            assert s1 > s0 and (rf, rl) == (rr[s0], rr[s1 - 1]) and rl - rf <= 20
+            assert (cmn, cmx) == (cc[s0:s1].min(), cc[s0:s1].max()) and cmx - cmn <= 63
+            if nxt is not None:
+                assert nxt[0] == s1 and (rr[s1] - rf > 20 or max(cmx, cc[s1]) - min(cmn, cc[s1]) > 63)
+        off, w = big.ltaps(k, quad=True)
+        r_last = np.concatenate([[rl] * (s1 - s0) for s0, s1, rf, rl, cmn, cmx in segs])
+        c_max = np.concatenate([[cmx] * (s1 - s0) for s0, s1, rf, rl, cmn, cmx in segs])
+        assert np.array_equal(off.numpy(), ((r_last - rr) * 96 + (c_max - cc)) * 8)          # 96 elements per LDS row
+        assert len(segs) <= len(std.segments(k))
+    assert len(big.segments(4)) <= 5 < len(std.segments(4))                                  # the diagonal: 8 standard segments
+
+
+def test_large_window_random_batches_vs_oracle_and_argument_errors():
+    """Ragged batches, every padding regime, skipped entries through blur_image_list with the extent hint (which selects
+    the large window for launches of one or two images) and through dib_blur_step; fp32 images / DIB_ACC_FP32 refuse it."""
+    from detectinblur_amd import _lib, blur_ops
+    from detectinblur_amd.models import blur_functions as BF
+    rs = np.random.RandomState(2025)
+    for trial in range(12):
+        n = 1 + trial % 2
+        imgs, psfs, dicts = [], [], []
+        for i in range(n):
+            C = (3, 1, 2)[(trial + i) % 3]
+            shape = [(C, 97, 301), (C, 65, 65), (C, 33, 140), (C, 130, 257), (C, 40, 50), (C, 200, 66)][(trial + i) % 6]
+            imgs.append(rs.random_sample(shape).astype(np.float16))
+            a = np.zeros((128, 128), np.float64)
+            m, sp = 20 + 15 * (trial % 5), 20 + 4 * trial
+            rr = np.clip(rs.randint(-sp, sp + 1, m) + 63, 0, 127); cc = np.clip(rs.randint(-sp // 3 - 1, sp // 3 + 2, m) + 63, 0, 127)
+            a[rr, cc] = rs.random_sample(m) + 0.01
+            h = O.to_half_like_torch(a * 0.2)
+            psfs.append(h)
+            r_, c_ = np.nonzero(h)
+            from detectinblur_amd import transforms as T
+            dicts.append({"blurring": True, "psf_taps": len(r_), "psf_extent": (int(r_.min()), int(r_.max()), int(c_.min()), int(c_.max())),
+                          "psf_segments": (T.count_tap_segments(h, T.STANDARD_WINDOW), T.count_tap_segments(h, T.LARGE_WINDOW))})
+            # the host-side hint counts what the device's compaction produces (no weight underflows here)
+            for lw, k in ((False, 0), (True, 1)):
+                assert len(blur_ops.compact_psfs([_dev(h)], normalize=True, large_window=lw).segments(0)) == dicts[-1]["psf_segments"][k]
+        std, big = sum(d["psf_segments"][0] for d in dicts), sum(d["psf_segments"][1] for d in dicts)
+        assert blur_ops.large_window_pays(dicts, n) == (2.4 * std > 5.0 * big + 6.0)
+        want = [a.copy() for a in imgs]
+        O.blur_image_list(want, dicts, psfs)
+        got = [_dev(a) for a in imgs]
+        BF.blur_image_list(got, dicts, [_dev(p) for p in psfs])          # the policy picks the window
+        for g, w in zip(got, want):
+            assert np.array_equal(_bits(g.cpu().numpy()).reshape(w.shape), _bits(w))
+        outs = blur_ops.blur_step([_dev(a) for a in imgs], list(range(n)), [_dev(p) for p in psfs], large_window=True)      # forced
+        for g, w in zip(outs, want):
+            assert np.array_equal(_bits(g.cpu().numpy()).reshape(w.shape), _bits(w))
+    assert not blur_ops.large_window_pays(dicts * 3, 3)
+    tabs = blur_ops.compact_psfs([_dev(psfs[0])], normalize=True, large_window=True)
+    with pytest.raises(_lib.DibError):
+        blur_ops.sparse_blur([torch.rand(3, 80, 90, device="cuda")], [0], tabs)                                   # fp32 image
+    with pytest.raises(_lib.DibError):
+        blur_ops.sparse_blur([torch.rand(3, 80, 90, device="cuda").half()], [0], tabs, _lib.DIB_ACC_FP32)

@@ -111,32 +111,24 @@ def test_evaluate_main_full_size_ensemble_sweep(tmp_path, monkeypatch, capsys):
     assert any(f.startswith("events.out.tfevents") for f in os.listdir(tmp_path / "tb"))
 
 
-def test_two_runs_of_evaluate_main_print_identical_coco_stats(tmp_path, capsys):
-    """Evaluation is reproducible on the GPU: the same `evaluate.main` command twice -- native-size images (the resize path of
-    the input transform), on-the-fly PSFs from seeded loader workers, HIP blur, box growth, graphed trunk (captured in the
-    first run, replayed and re-captured in the second), RoI heads, COCO evaluator -- gives the same detections bit for bit and
-    the same twelve COCO statistics (round 3 could not: MIOpen's atomically accumulating kernels in the inference path,
-    profiles/r4_nondeterminism.txt; reference engine.py:275-392)."""
-    from detectinblur_amd import evaluate
-    runs = []
-    for k in range(2):
-        args = evaluate.build_parser().parse_args([
-            "--synthetic", "--synthetic_images", "5", "--synthetic_size", "480", "640", "-j", "2", "--blur_eval", "--gpu_blur",
-            "--expand_target_boxes", "--early_stop", "3"])
-        res = evaluate.main(args)                       # the 15-cell sweep, one detector
-        text = capsys.readouterr().out
-        runs.append((res, [l for l in text.splitlines() if "Average Precision" in l or "Average Recall" in l]))
-    (a, ta), (b, tb) = runs
-    assert len(ta) == 12 * 15 and ta == tb
-    assert sorted(a) == sorted(b) and len(a) == 15
-    total = 0
-    for cell in a:
-        ra, rb = a[cell], b[cell]
-        assert np.array_equal(ra.coco_eval["bbox"].stats, rb.coco_eval["bbox"].stats), cell
-        assert sorted(ra["detections"]) == sorted(rb["detections"]) and len(ra["detections"]) == 4
-        for k in ra["detections"]:
-            for f in ("boxes", "scores", "labels"):
-                assert torch.equal(ra["detections"][k][f], rb["detections"][k][f]), (cell, k, f)
-            assert torch.equal(ra["targets"][k], rb["targets"][k])
-            total += len(ra["detections"][k]["boxes"])
-    assert total > 0
+def test_two_runs_of_evaluate_main_print_identical_coco_stats(tmp_path):
+    """Evaluation is reproducible on the GPU: the same `evaluate.main` command in two fresh processes -- native-size images (the
+    resize path of the input transform), on-the-fly PSFs from seeded loader workers, HIP blur (standard and large window), box
+    growth, eager and graphed trunk, RoI heads, COCO evaluator, all 15 sweep cells -- prints the same 180 statistic lines and
+    produces the same detections and expanded ground truth bit for bit (round 3 could not: MIOpen's atomically accumulating
+    kernels in the inference path, profiles/r4_nondeterminism.txt; reference engine.py:275-392).  (Two runs inside ONE process
+    are not the claim: MIOpen's choice among equally ranked kernels depends on the workspace the allocator can spare at
+    that moment.)"""
+    from tests import _gpu_children
+    from tests.test_ddp_gpu import _run_child
+    argv = ["--synthetic", "--synthetic_images", "5", "--synthetic_size", "480", "640", "-j", "2", "--blur_eval", "--gpu_blur",
+            "--expand_target_boxes", "--early_stop", "3"]
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    a = _run_child(_gpu_children.evaluate_main_digest, tmp_path / "a", argv)
+    b = _run_child(_gpu_children.evaluate_main_digest, tmp_path / "b", argv)
+    assert len(a["stat_lines"]) == 12 * 15 and a["stat_lines"] == b["stat_lines"]
+    assert sorted(a["cells"]) == sorted(b["cells"]) and len(a["cells"]) == 15
+    for cell in a["cells"]:
+        assert a["cells"][cell] == b["cells"][cell], cell
+        assert a["cells"][cell]["images"] == 4
+    assert sum(c["boxes"] for c in a["cells"].values()) > 0

@@ -56,6 +56,7 @@ def test_blurimage_matches_reference(golden, mode, capsys):
         rr, cc = np.nonzero(psf > 0)
         assert bd["psf_extent"] == (rr.min(), rr.max(), cc.min(), cc.max())
         assert bd["psf_taps"] == len(rr)
+        assert 1 <= bd["psf_segments"][1] <= bd["psf_segments"][0] <= len(rr)
     # both RNG streams end where the reference's end
     assert random.random() == want["next_random"]
     assert float(np.random.uniform()) == want["next_np"]
