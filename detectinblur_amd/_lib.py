@@ -41,6 +41,8 @@ _SIGNATURES = {
     "dib_blur_step": (ctypes.c_int, [_c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      _c_void_pp, _c_void_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "dib_blur_step_packed": (ctypes.c_int, [_c_void_pp, _c_int_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "dib_blur_step_release": (ctypes.c_int, []),
     "dib_normalize_pad": (ctypes.c_int, [_c_void_pp, ctypes.c_int, _c_int_p, _c_int_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

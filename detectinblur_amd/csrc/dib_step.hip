@@ -99,3 +99,12 @@ extern "C" int dib_blur_step_release(void) {
   }
   return DIB_OK;
 }
+
+// The same call with its nine host arrays packed into two (a ctypes caller pays ~1.2 us per array it builds):
+//   ptrs = psf_ptrs[num_psfs] | in_dev[B] | out_dev[B];   ints = C[B] | H[B] | W[B] | table_index[B]
+extern "C" int dib_blur_step_packed(const void *const *ptrs, const int *ints, int psf_dtype, int num_psfs, int K, int normalize, int B,
+                                    int dtype, int acc_mode, void *tables_dev, int flags, void *stream) {
+  if (!ptrs || !ints || num_psfs < 0 || B < 0) { set_error("dib_blur_step_packed: null pointer or negative count"); return DIB_EINVAL; }
+  return dib_blur_step(ptrs, psf_dtype, num_psfs, K, normalize, ptrs + num_psfs, (void *const *)(ptrs + num_psfs + B), ints, ints + B, ints + 2 * B,
+                       ints + 3 * B, B, dtype, acc_mode, tables_dev, flags, stream);
+}

@@ -95,9 +95,17 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_lev
             for i in idx:
                 images_GPU[i] = _post_ops(images_GPU[i], add_noise, noise_level, add_block, add_jpeg_artifact, jpeg_compressor)
         return None
-    Ks = {psfs_GPU[i].shape[0] for i in idx}
-    dts = {psfs_GPU[i].dtype for i in idx}
-    if len(Ks) != 1 or len(dts) != 1:
+    p0 = psfs_GPU[idx[0]]
+    K0, dt0 = p0.shape[0], p0.dtype
+    mixed = False
+    for i in idx:
+        p = psfs_GPU[i]
+        if p.shape[0] != K0 or p.dtype != dt0:
+            mixed = True
+            break
+    if mixed:
+        Ks = {psfs_GPU[i].shape[0] for i in idx}
+        dts = {psfs_GPU[i].dtype for i in idx}
         # mixed canvases / dtypes in one batch: one launch group per (K, dtype)
         for K in Ks:
             for dt in dts:
@@ -114,18 +122,15 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_lev
 
 
 def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=None, psfs_complete=False):
-    K = psfs_GPU[idx[0]].shape[0]
-    if K <= 129:
-        for i in idx:
-            sh = images_GPU[i].shape
-            if sh[-2] == 64 or sh[-1] == 64:
-                _check_shapes(images_GPU[i], K)       # raises what the reference's reflect padding raises
+    # (an image that is exactly 64 high or wide under a 128-wide PSF raises in the library what the reference's reflect padding
+    # raises: DibError is a RuntimeError carrying "Padding size should be less than the corresponding input dimension")
     psfs = None
     if tables is None:
         psfs = []
+        idt = images_GPU[idx[0]].dtype
         for i in idx:
             p = psfs_GPU[i]
-            if p.dtype != images_GPU[i].dtype:
+            if p.dtype != idt:
                 p = p.to(images_GPU[i].dtype)
                 psfs_complete = False           # the conversion was just queued on the current stream
             psfs.append(p)
@@ -141,7 +146,8 @@ def _blur_group(images_GPU, psfs_GPU, idx, acc_mode, blur_dicts=None, tables=Non
         if taps is not None:
             perm.sort(key=taps.__getitem__, reverse=True)      # stable: equal tap counts keep their order
     if tables is None:
-        large = blur_dicts is not None and blur_ops.large_window_pays([blur_dicts[i] for i in idx], len(idx))
+        large = (blur_dicts is not None and len(idx) <= blur_ops.LARGE_WINDOW_MAX_IMAGES
+                 and blur_ops.large_window_pays([blur_dicts[i] for i in idx], len(idx)))
         outs = blur_ops.blur_step([images_GPU[idx[k]] for k in perm], perm, psfs, True, acc_mode, psfs_complete, large)
     else:
         outs = blur_ops.sparse_blur([images_GPU[idx[k]] for k in perm], perm, tables, acc_mode)

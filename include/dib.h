@@ -128,6 +128,10 @@ int dib_blur_step(const void *const *psf_ptrs, int psf_dtype, int num_psfs, int 
                   const void *const *in_dev, void *const *out_dev, const int *C, const int *H, const int *W,
                   const int *table_index, int B, int dtype, int acc_mode, void *tables_dev, int flags,
                   void *stream);
+/* dib_blur_step with its nine host arrays packed into two (for callers that pay per array they marshal, e.g. ctypes):
+ * ptrs = psf_ptrs[num_psfs] | in_dev[B] | out_dev[B];  ints = C[B] | H[B] | W[B] | table_index[B]. */
+int dib_blur_step_packed(const void *const *ptrs, const int *ints, int psf_dtype, int num_psfs, int K, int normalize, int B,
+                         int dtype, int acc_mode, void *tables_dev, int flags, void *stream);
 int dib_blur_step_release(void);
 
 /* ---------------------------------------------------------------------------------------
