@@ -13,8 +13,10 @@ import os as _os
 
 # MIOpen picks each convolution's kernel by timing every applicable solver the first time it sees a
 # shape (~90 s for this detector at b=8 x 800x1344 on a fresh machine) and remembers the result in a
-# "user find-db".  `miopen_db/` ships that database for the BASELINE shapes on gfx950, so a fresh
-# process warms up in about a second.  The process works on a PRIVATE COPY of it (a temporary directory):
+# "user find-db".  `miopen_db/` ships that database for every shape the bench, the drivers (800 x 1333 and
+# native COCO sizes) and the GPU tests meet on gfx950 (scratch/fill_miopen_db.sh regenerates it), so a fresh
+# process warms up in about a second and -- the choice being recorded, not re-measured -- every process
+# picks the same kernels.  The process works on a PRIVATE COPY of it (a temporary directory):
 # MIOpen appends what it learns about new shapes to the user db, and a later process that read those
 # records chose other kernels than the process that wrote them -- the same `evaluate.main` command gave
 # different last bits from one run to the next (tests/test_full_size_gpu.py), and a process that ran in
