@@ -66,3 +66,32 @@ def test_product_package_never_imports_the_oracle():
             if "oracle" in src and ("sys.path" in src and "oracle" in src.split("sys.path")[1][:200]):
                 bad.append(os.path.join(d, fn) + " (sys.path)")
     assert not bad, bad
+
+
+def test_every_process_gets_a_private_copy_of_the_shipped_miopen_find_db():
+    """`import detectinblur_amd` points MIOPEN_USER_DB_PATH at a temporary copy of detectinblur_amd/miopen_db (MIOpen appends
+    to its user db; a shared one made kernel choices drift from process to process), respects an explicit setting, and works on
+    the shipped directory itself only on request."""
+    import subprocess
+    import sys
+    code = "import os, detectinblur_amd; p = os.environ.get('MIOPEN_USER_DB_PATH'); print(p); print(sorted(os.listdir(p)) if p and os.path.isdir(p) else None)"
+    shipped = os.path.join(ROOT, "detectinblur_amd", "miopen_db")
+    files = sorted(f for f in os.listdir(shipped) if os.path.isfile(os.path.join(shipped, f)))
+    assert files and all(f.endswith(".ufdb.txt") for f in files)
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("MIOPEN_USER_DB_PATH", "DIB_MIOPEN_DB_INPLACE", "DIB_NO_MIOPEN_DB")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        path, listing = r.stdout.strip().splitlines()[-2:]
+        return path, listing
+
+    path, listing = run({})
+    assert path != shipped and "dib_miopen_db_" in path and listing == str(files)
+    assert not os.path.exists(path)                                   # removed when the process exits
+    assert run({"MIOPEN_USER_DB_PATH": "/tmp"})[0] == "/tmp"
+    assert run({"DIB_MIOPEN_DB_INPLACE": "1"})[0] == shipped
+    assert run({"DIB_NO_MIOPEN_DB": "1"})[0] == "None"
+    lines = sum(1 for _ in open(os.path.join(shipped, files[0])))
+    assert lines >= 500       # the bench's, the drivers' and the tests' shapes (scratch/fill_miopen_db.sh), not only the b = 8 training ones
