@@ -5,7 +5,8 @@ root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", "prof_r4")
 def counters(sub, skip=6):
     out = {}
-    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    # gpurun merges every call's files into gpurun_out/: take the newest run's file only
+    for f in sorted(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
         acc = {}
         for r in csv.DictReader(open(f)):
             if "blur_quad" in r["Kernel_Name"]:
@@ -19,13 +20,13 @@ for sub in ("fetch_warm", "write_warm", "sq", "sq2"):
     warm.update(counters(sub, 2))
 for sub in ("fetch_cold", "write_cold"):
     cold.update(counters(sub, 12))
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(stats)))
 blur = [r for r in rows if "blur_quad" in r["Name"] and "<0, 128>" in r["Name"]][0]      # bit-exact, 128 canvas
 # the launches of bench.py's roofline loop alone (5 x (8 + 200) back-to-back launches, the last warm ones of this kernel in the
 # trace: the eager / graph steps in front of them alternate with the compaction kernel and run under the profiler's
 # per-dispatch overhead, the cold rotation behind them misses the Infinity Cache)
-trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)[0]
+trace = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
 tr = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace))
              if "blur_quad_f16_kernel<0, 128>" in r["Kernel_Name"] or "psf_compact" in r["Kernel_Name"]))
 runs, cur = [], []
