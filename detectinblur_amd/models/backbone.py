@@ -214,6 +214,10 @@ class _Gemm1x1(torch.autograd.Function):
             dx = torch.mm(gf, weight.reshape(Co, Ci)).view(N, H, W, Ci).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dw = torch.mm(gf.t(), x.permute(0, 2, 3, 1).reshape(-1, Ci)).view(weight.shape)
+            if dw.stride() != weight.stride():
+                # a 1x1 kernel's [Co, Ci, 1, 1] memory is the same contiguous or channels-last: hand the gradient over with the
+                # parameter's own strides, or DDP's bucket views (gradient_as_bucket_view) copy it instead of aliasing it
+                dw = dw.as_strided(weight.shape, weight.stride())
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = gf.sum(0)
         return dx, dw, db

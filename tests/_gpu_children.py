@@ -152,6 +152,44 @@ def evaluate_main_digest(out_path, argv):
     _guarded(_evaluate_main_digest, out_path, (argv,))
 
 
+def _driver_under_one_rank_rccl(which, argv):
+    """`train.main` / `evaluate.main` in distributed mode over a ONE-RANK RCCL process group (RANK / WORLD_SIZE / LOCAL_RANK set as
+    torchrun sets them): utils.init_distributed_mode picks "nccl", the model is wrapped in DistributedDataParallel, the samplers
+    are DistributedSamplers, metrics and COCO records go through the RCCL collectives of utils.all_gather / reduce_dict."""
+    _one_rank_env()
+    import contextlib
+    import io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    buf = io.StringIO()
+    out = {}
+    with contextlib.redirect_stdout(buf):
+        if which == "train":
+            from detectinblur_amd import train
+            train.main(train.build_parser().parse_args(list(argv)))
+        else:
+            from detectinblur_amd import evaluate
+            res = evaluate.main(evaluate.build_parser().parse_args(list(argv)))
+            out["cells"] = {k: {"stats": [float(x) for x in v.coco_eval["bbox"].stats], "images": len(v["detections"])} for k, v in res.items()}
+    out["backend"] = dist.get_backend() if dist.is_initialized() else None
+    out["world"] = dist.get_world_size() if dist.is_initialized() else None
+    text = buf.getvalue()
+    out["distributed_line"] = "| distributed init (rank 0)" in text
+    out["loss_lines"] = len([l for l in text.splitlines() if "loss_classifier" in l])
+    out["stat_lines"] = len([l for l in text.splitlines() if "Average Precision" in l])
+    out["tail"] = text[-600:]
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def driver_under_one_rank_rccl(out_path, which, argv):
+    _guarded(_driver_under_one_rank_rccl, out_path, (which, argv))
+
+
 def ddp_one_rank(out_path, fused):
     _guarded(_ddp_one_rank, out_path, (fused,))
 

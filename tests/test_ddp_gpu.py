@@ -73,3 +73,32 @@ def test_bench_distributed_branch_with_one_rank(tmp_path):
     sw = d["eval_sweep"]
     assert sw["n_gpus"] == 1 and sw["sharding"].startswith("DistributedSampler") and len(sw["cells"]) == 15
     assert set(sw["images_per_s_with_merge"]) == set(sw["images_per_s"]) and all(v > 0 for v in sw["images_per_s_with_merge"].values())
+
+
+def test_train_main_and_evaluate_main_over_one_rank_rccl(tmp_path):
+    """configs[3] / configs[4] as the reference launches them (`python -m torch.distributed.launch ... train.py`, reference
+    train.py:186-205; evaluate.py:331-332) with the one rank a 1-GPU box has: the REAL drivers at 800 x 1333 in distributed
+    mode on the RCCL backend -- DDP-wrapped detector fed by a DistributedSampler over stored PSFs, blurred and clean evaluation
+    passes with their all_gather merges, checkpoint written by rank 0; then the 15-cell sweep of `evaluate.main` with its
+    DistributedSampler and per-cell merges.  (Two gloo ranks run the same drivers on the CPU: tests/test_drivers_two_ranks.py.)"""
+    import torch
+    from tests import _gpu_children
+    from tests.test_full_size_gpu import _psf_store
+    store = _psf_store(tmp_path, 32)
+    out_dir = tmp_path / "weights"
+    (tmp_path / "t").mkdir(); (tmp_path / "e").mkdir()
+    r = _run_child(_gpu_children.driver_under_one_rank_rccl, tmp_path / "t", "train", [
+        "--synthetic", "--synthetic_images", "32", "--synthetic_size", "800", "1333", "-b", "8", "-j", "2", "--epochs", "1",
+        "--blur_train", "--gpu_blur", "--use_stored_psfs", "--stored_psf_directory", store, "--stored_psf_count", "32",
+        "--param_index", "1", "--low_exposure", "--expand_target_boxes", "--early_stop", "2", "--lr", "0.002", "--print_freq", "1",
+        "--output_dir", str(out_dir)], timeout=2400)
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["distributed_line"], r["tail"]
+    assert r["loss_lines"] >= 2 and r["stat_lines"] >= 2, r["tail"]
+    ck = torch.load(out_dir / "model_0.pth", map_location="cpu", weights_only=False)
+    assert not any(k.startswith("module.") for k in ck["model"]) and len(ck["model"]) == 295
+    assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.is_floating_point())
+    e = _run_child(_gpu_children.driver_under_one_rank_rccl, tmp_path / "e", "evaluate", [
+        "--synthetic", "--synthetic_images", "3", "--synthetic_size", "800", "1333", "-j", "2", "--blur_eval", "--gpu_blur",
+        "--expand_target_boxes", "--early_stop", "1", "--resume", str(out_dir / "model_0.pth")], timeout=2400)
+    assert e["backend"] == "nccl" and e["world"] == 1 and len(e["cells"]) == 15, e["tail"]
+    assert all(c["images"] == 2 and len(c["stats"]) == 12 for c in e["cells"].values())
