@@ -74,6 +74,17 @@ _SIGNATURES = {
                                ctypes.c_void_p, ctypes.c_void_p]),
     "dib_nms_batched": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_box_match": (ctypes.c_int, [ctypes.c_void_p, _c_int_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                     ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_box_encode_matched": (ctypes.c_int, [ctypes.c_void_p, _c_int_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_box_decode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_box_pool": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, _c_int_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                    ctypes.c_void_p]),
+    "dib_box_labels": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_int_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p]),
     "dib_coco_box_iou": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p, ctypes.c_void_p]),
     "dib_bias_act_nhwc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
@@ -132,6 +143,22 @@ def lib():
 def check(code):
     if code != 0:
         raise DibError(code, lib().dib_last_error().decode("utf-8", "replace"))
+
+
+_raw_stream = None
+
+
+def stream_of(tensor):
+    """hipStream_t (as an int) of torch's current stream on the tensor's device.  torch's raw accessor is ~30x cheaper than building
+    a torch.cuda.Stream object (8 us of host time per call: measured, scratch/t_detect_cost.py), which is most of a small launch."""
+    global _raw_stream
+    import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        idx = tensor.device.index
+        return _raw_stream(idx if idx is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(tensor.device).cuda_stream
 
 
 _INT_ARRAYS, _PTR_ARRAYS = {}, {}      # ctypes array TYPES by length (building the type is most of a small array's cost)

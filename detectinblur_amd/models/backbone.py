@@ -60,7 +60,7 @@ class _BiasAct(torch.autograd.Function):
     def forward(ctx, x, bias, residual, relu, state=None):
         from .. import _lib
         N, C, H, W = x.shape
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = _lib.stream_of(x)
         res = residual.data_ptr() if residual is not None else None
         ctx.relu, ctx.has_res, ctx.masked, ctx.state = bool(relu), residual is not None, False, state
         if (relu and RELU_MASK and any(ctx.needs_input_grad[:3]) and C % 4 == 0
@@ -94,7 +94,7 @@ class _BiasAct(torch.autograd.Function):
                 grad = grad.clone(memory_format=torch.channels_last)
             out = torch.empty_like(grad)     # not in place: autograd may hand the same gradient tensor to another node
             _lib.check(_lib.lib().dib_relu_mask_backward(grad.data_ptr(), mask.data_ptr(), out.data_ptr(), grad.numel(),
-                                                         torch.cuda.current_stream().cuda_stream))
+                                                         _lib.stream_of(grad)))
             grad = out
         elif ctx.relu:
             (y,) = ctx.saved_tensors
@@ -288,10 +288,10 @@ class _BlockEntry(torch.autograd.Function):
                 if not g_skip.is_contiguous(memory_format=torch.channels_last) or g_skip.data_ptr() & 15:
                     g_skip = g_skip.clone(memory_format=torch.channels_last)
                 _lib.check(_lib.lib().dib_add_relu_mask(dx.data_ptr(), g_skip.data_ptr(), mask.data_ptr() if mask is not None else None,
-                                                        dx.numel(), torch.cuda.current_stream().cuda_stream))
+                                                        dx.numel(), _lib.stream_of(dx)))
             elif mask is not None:
                 _lib.check(_lib.lib().dib_relu_mask_backward(dx.data_ptr(), mask.data_ptr(), dx.data_ptr(), dx.numel(),
-                                                             torch.cuda.current_stream().cuda_stream))
+                                                             _lib.stream_of(dx)))
             if mask is not None:
                 # tell the producing _BiasAct which gradient tensor already carries its ReLU mask; it re-applies the mask (idempotent
                 # and linear, so always correct) to anything else -- e.g. the sum autograd forms when the output has a second consumer
@@ -327,7 +327,7 @@ class _DownEntry(torch.autograd.Function):
         dxs, dwd, _ = torch.ops.aten.convolution_backward(cl(g_d), xs, wd, None, *args, [need_x, need_wd, False])
         if need_x:
             dx, dxs = cl(dx), cl(dxs)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _lib.stream_of(dx)
             if ctx.s == 1:
                 _lib.check(_lib.lib().dib_add_relu_mask(dx.data_ptr(), dxs.data_ptr(), None, dx.numel(), stream))
             else:
@@ -362,7 +362,7 @@ class _FoldAll(torch.autograd.Function):
             P([w.data_ptr() for w in weights]), P([b.weight.data_ptr() for b in bns]), P([b.bias.data_ptr() for b in bns]),
             P([b.running_mean.data_ptr() for b in bns]), P([b.running_var.data_ptr() for b in bns]), _lib.int_array(cos),
             _lib.int_array(inner), n, float(bns[0].eps), P([t.data_ptr() for t in wfs]), P([t.data_ptr() for t in scales]),
-            P([t.data_ptr() for t in shifts]), torch.cuda.current_stream().cuda_stream))
+            P([t.data_ptr() for t in shifts]), _lib.stream_of(wfs[0])))
         ctx.save_for_backward(flat)
         ctx.meta = (cos, inner)
         ctx.mark_non_differentiable(*shifts)
@@ -392,7 +392,7 @@ class _FoldAll(torch.autograd.Function):
             P = _lib.ptr_array
             _lib.check(_lib.lib().dib_scale_rows_multi(
                 P([g.data_ptr() for g in gs]), P([flat.data_ptr() + 4 * offs[k] for k in ks]), _lib.int_array([cos[k] for k in ks]),
-                _lib.int_array([inner[k] for k in ks]), len(ks), P([o.data_ptr() for o in outs]), torch.cuda.current_stream().cuda_stream))
+                _lib.int_array([inner[k] for k in ks]), len(ks), P([o.data_ptr() for o in outs]), _lib.stream_of(outs[0])))
             for k, o in zip(ks, outs):
                 dws[k] = o
         return (None,) + tuple(dws)
@@ -607,7 +607,7 @@ class _StemPool(torch.autograd.Function):
         out = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         arg = torch.empty((N * Ho * Wo * (C // 4),), dtype=torch.int16, device=x.device)
         _lib.check(_lib.lib().dib_stem_pool_forward(x.data_ptr(), bias.data_ptr(), out.data_ptr(), arg.data_ptr(), N, H, W, C,
-                                                    torch.cuda.current_stream().cuda_stream))
+                                                    _lib.stream_of(x)))
         ctx.shape = (N, C, H, W)
         ctx.save_for_backward(arg)
         return out
@@ -621,7 +621,7 @@ class _StemPool(torch.autograd.Function):
             g = g.clone(memory_format=torch.channels_last)
         gx = torch.empty((N, C, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
         _lib.check(_lib.lib().dib_stem_pool_backward(g.data_ptr(), arg.data_ptr(), gx.data_ptr(), N, H, W, C,
-                                                     torch.cuda.current_stream().cuda_stream))
+                                                     _lib.stream_of(g)))
         return gx, (gx.sum(dim=(0, 2, 3)) if ctx.needs_input_grad[1] else None)
 
 
@@ -690,7 +690,7 @@ class _TopDownMerge(torch.autograd.Function):
         ctx.top_shape = tuple(top.shape)
         ctx.mark_dirty(x)
         _lib.check(_lib.lib().dib_fpn_topdown_merge_nhwc(x.data_ptr(), bias.data_ptr(), top.data_ptr(), N, H, W, top.shape[2], top.shape[3], C,
-                                                         torch.cuda.current_stream().cuda_stream))
+                                                         _lib.stream_of(x)))
         return x
 
     @staticmethod

@@ -149,6 +149,89 @@ def match_batched(matcher, quality, valid):
     return matches
 
 
+# ---- the same bookkeeping as HIP launches (csrc/dib_detect.hip) for CUDA tensors --------------------------------------------
+# Ragged ground truth travels as ONE concatenated tensor + host offsets (no padding, no per-image copies).
+HIP_BOXES = True      # False: the tensor expressions above on the GPU as well (what the kernels are tested against)
+
+
+def hip_boxes_ok(*tensors):
+    return HIP_BOXES and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def cat_boxes(boxes_per_image):
+    """(gt_cat [T, 4] contiguous float32 -- None when T == 0 --, offsets: N + 1 host ints)"""
+    offs, t = [0], 0
+    for b in boxes_per_image:
+        t += int(b.shape[0])
+        offs.append(t)
+    if t == 0:
+        return None, offs
+    live = [b for b in boxes_per_image if b.shape[0]]
+    gt = (live[0] if len(live) == 1 else torch.cat(live)).contiguous()
+    return (gt.clone() if gt.data_ptr() % 16 else gt), offs
+
+
+def match_boxes_hip(matcher, gt_cat, offsets, cand, shared):
+    """Matcher(box_iou(gt_i, cand_i)) for every image in one or two launches: matches [N, M] int64 (index into image i's own
+    list, -1 / -2 as Matcher).  cand: [N, M, 4], or [M, 4] shared by every image."""
+    N = len(offsets) - 1
+    cand = cand.contiguous()
+    M = cand.shape[-2]
+    match = torch.empty((N, M), dtype=torch.int64, device=cand.device)
+    best = torch.empty(max(offsets[-1], 1), dtype=torch.int32, device=cand.device) if matcher.allow_low else None
+    _lib.check(_lib.lib().dib_box_match(gt_cat.data_ptr() if gt_cat is not None else None, _lib.int_array(offsets), N, cand.data_ptr(), M,
+                                        int(bool(shared)), float(matcher.high), float(matcher.low), int(bool(matcher.allow_low)),
+                                        best.data_ptr() if best is not None else None, match.data_ptr(),
+                                        _lib.stream_of(cand)))
+    return match
+
+
+def encode_matched_hip(coder, gt_cat, offsets, match, cand, shared, want_targets=True, want_matched=False):
+    """(BoxCoder.encode(gt[match.clamp(min=0)], cand) [N, M, 4] | None, the matched boxes [N, M, 4] | None) in one launch."""
+    N = len(offsets) - 1
+    cand, match = cand.contiguous(), match.contiguous()
+    M = cand.shape[-2]
+    tg = torch.empty((N, M, 4), dtype=torch.float32, device=cand.device) if want_targets else None
+    mb = torch.empty((N, M, 4), dtype=torch.float32, device=cand.device) if want_matched else None
+    wx, wy, ww, wh = coder.weights
+    _lib.check(_lib.lib().dib_box_encode_matched(gt_cat.data_ptr() if gt_cat is not None else None, _lib.int_array(offsets), N, match.data_ptr(),
+                                                 cand.data_ptr(), M, int(bool(shared)), float(wx), float(wy), float(ww), float(wh),
+                                                 tg.data_ptr() if tg is not None else None, mb.data_ptr() if mb is not None else None,
+                                                 _lib.stream_of(cand)))
+    return tg, mb
+
+
+def pool_boxes_hip(proposals, gt_cat, offsets, g_pad):
+    """[N, P + g_pad, 4]: the proposals of every image followed by its ground truth and [0, 0, 1, 1] padding rows, in one launch."""
+    proposals = proposals.contiguous()
+    N, P = proposals.shape[:2]
+    out = torch.empty((N, P + g_pad, 4), dtype=torch.float32, device=proposals.device)
+    _lib.check(_lib.lib().dib_box_pool(proposals.data_ptr(), P, gt_cat.data_ptr() if gt_cat is not None else None, _lib.int_array(offsets), N, g_pad,
+                                       out.data_ptr(), _lib.stream_of(proposals)))
+    return out
+
+
+def pool_labels_hip(match, gt_labels_cat, offsets, ok, P):
+    """Class of every pool row [N, M] int64 (0 background, -1 ignored / padding) from the matches, in one launch."""
+    match = match.contiguous()
+    N, M = match.shape
+    ok = ok.contiguous() if ok is not None else None
+    out = torch.empty((N, M), dtype=torch.int64, device=match.device)
+    _lib.check(_lib.lib().dib_box_labels(match.data_ptr(), gt_labels_cat.data_ptr() if gt_labels_cat is not None else None, _lib.int_array(offsets), N,
+                                         ok.data_ptr() if ok is not None else None, P, M, out.data_ptr(), _lib.stream_of(match)))
+    return out
+
+
+def decode_boxes_hip(coder, deltas, anchors):
+    """BoxCoder.decode(deltas [R, 4], anchors [A, 4] repeated R / A times) -> [R, 4] in one launch (no repeated anchor tensor)."""
+    deltas, anchors = deltas.contiguous(), anchors.contiguous()
+    out = torch.empty_like(deltas)
+    wx, wy, ww, wh = coder.weights
+    _lib.check(_lib.lib().dib_box_decode(deltas.data_ptr(), anchors.data_ptr(), deltas.shape[0], anchors.shape[0], float(wx), float(wy), float(ww),
+                                         float(wh), float(coder.clip), out.data_ptr(), _lib.stream_of(deltas)))
+    return out
+
+
 def sample_pos_neg(labels_per_image, batch_size, positive_fraction):
     """Random subset of at most `batch_size` entries per image with up to `positive_fraction`
     positives (label >= 1), rest negatives (label == 0).  Returns per-image index tensors."""
@@ -222,7 +305,7 @@ def nms(boxes, scores, iou_threshold):
     keep = torch.empty(n, dtype=torch.int64, device=b.device)
     count = torch.empty(1, dtype=torch.int32, device=b.device)
     _lib.check(l.dib_nms(b.data_ptr(), n, float(iou_threshold), ws.data_ptr(), keep.data_ptr(), count.data_ptr(),
-                         torch.cuda.current_stream().cuda_stream))
+                         _lib.stream_of(b)))
     return order[keep[:int(count.item())]]
 
 
@@ -251,7 +334,7 @@ def nms_sets_sorted(boxes, valid, iou_threshold):
     v = None if valid is None else valid.to(torch.uint8).contiguous()
     ws = torch.empty(B * l.dib_nms_workspace_bytes(n), dtype=torch.uint8, device=b.device)
     _lib.check(l.dib_nms_batched(b.data_ptr(), v.data_ptr() if v is not None else None, B, n, float(iou_threshold),
-                                 ws.data_ptr(), keep.data_ptr(), count.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                 ws.data_ptr(), keep.data_ptr(), count.data_ptr(), _lib.stream_of(b)))
     return keep, count
 
 
@@ -275,7 +358,7 @@ def coco_box_iou(dt, gt, iscrowd=None):
     out = torch.zeros((n, m), dtype=torch.float64, device=d.device)
     c = None if iscrowd is None else iscrowd.to(device=d.device, dtype=torch.uint8).contiguous()
     _lib.check(_lib.lib().dib_coco_box_iou(d.data_ptr(), g.data_ptr(), c.data_ptr() if c is not None else None, m, n,
-                                           out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                           out.data_ptr(), _lib.stream_of(d)))
     return out.t()
 
 
@@ -342,7 +425,7 @@ class _RoIAlignHIP(torch.autograd.Function):
         out = torch.empty((K, C, pooled, pooled), dtype=torch.float32, device=feat.device)
         _lib.check(_lib.lib().dib_roi_align_forward(feat.data_ptr(), rois.data_ptr(), K, C, H, W, float(spatial_scale), pooled,
                                                     sampling_ratio, int(aligned), out.data_ptr(),
-                                                    torch.cuda.current_stream().cuda_stream))
+                                                    _lib.stream_of(out)))
         ctx.save_for_backward(rois)
         ctx.meta = (tuple(feat.shape), float(spatial_scale), pooled, sampling_ratio, int(aligned))
         return out
@@ -355,7 +438,7 @@ class _RoIAlignHIP(torch.autograd.Function):
         grad = torch.zeros(shape, dtype=torch.float32, device=grad_out.device)
         g = grad_out.contiguous().float()
         _lib.check(_lib.lib().dib_roi_align_backward(g.data_ptr(), rois.data_ptr(), rois.shape[0], C, H, W, scale, pooled, sr,
-                                                     aligned, grad.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                                     aligned, grad.data_ptr(), _lib.stream_of(grad)))
         return grad, None, None, None, None, None
 
 
@@ -378,7 +461,7 @@ class _RoIAlignNHWC(torch.autograd.Function):
         _lib.check(_lib.lib().dib_roi_align_nhwc_forward(
             _lib.ptr_array([f.data_ptr() for f in feats]), hs, ws, sc, len(feats), rois.data_ptr(),
             level.data_ptr() if level is not None else None, K, C, pooled, sampling_ratio, int(aligned), out.data_ptr(),
-            torch.cuda.current_stream().cuda_stream))
+            _lib.stream_of(out)))
         ctx.save_for_backward(rois, level) if level is not None else ctx.save_for_backward(rois)
         ctx.meta = ([tuple(f.shape) for f in feats], [float(s) for s in scales], pooled, sampling_ratio, int(aligned))
         return out
@@ -396,7 +479,7 @@ class _RoIAlignNHWC(torch.autograd.Function):
         _lib.check(_lib.lib().dib_roi_align_nhwc_backward(
             g.data_ptr(), hs, ws, sc, len(shapes), rois.data_ptr(), level.data_ptr() if level is not None else None,
             rois.shape[0], shapes[0][1], pooled, sr, aligned, _lib.ptr_array([x.data_ptr() for x in grads]),
-            torch.cuda.current_stream().cuda_stream))
+            _lib.stream_of(g)))
         return (None, None, None, None, None, None) + tuple(grads)
 
 

@@ -85,6 +85,8 @@ class RoIHeads(nn.Module):
         # every image at once (ground truth padded to the longest list, padding rows [0, 0, 1, 1] as in the per-image form):
         # the per-image loop below is ~30 small launches per image that the host issues slower than the GPU runs them
         N = boxes.shape[0]
+        if ops.hip_boxes_ok(boxes, *gt_boxes) and N <= 32 and max(g.shape[0] for g in gt_boxes) <= 256 and ok.dtype == torch.bool:
+            return self._select_hip(boxes, ok, gt_boxes, gt_labels)
         gt, valid = ops.pad_boxes(gt_boxes)
         G = gt.shape[1]
         unit = _unit_boxes(1, boxes)[None].expand(N, G, 4)
@@ -112,6 +114,26 @@ class RoIHeads(nn.Module):
         ref = gt.gather(1, matched.gather(1, sel)[..., None].expand(-1, -1, 4))      # images without boxes: zeros
         reg = self.box_coder.encode(ref.reshape(-1, 4), rois.reshape(-1, 4))
         return list(rois), labs.reshape(-1), reg, sel_ok.reshape(-1)
+
+    def _select_hip(self, boxes, ok, gt_boxes, gt_labels):
+        """The batched form above with pool, matching, labels and target encoding as one launch each (csrc/dib_detect.hip);
+        the sampler in between is the same tensor code, fed the same shapes, so it draws the same rows."""
+        P, S = boxes.shape[1], self.batch_size_per_image
+        gt_cat, offs = ops.cat_boxes(gt_boxes)
+        live_labels = [l for l in gt_labels if l.shape[0]]
+        lab_cat = None if not live_labels else (live_labels[0] if len(live_labels) == 1 else torch.cat(live_labels)).to(torch.int64).contiguous()
+        g_pad = max(max(g.shape[0] for g in gt_boxes), 1)
+        cands = ops.pool_boxes_hip(boxes, gt_cat, offs, g_pad)                       # ground truth joins the pool
+        m = ops.match_boxes_hip(self.matcher, gt_cat, offs, cands, shared=False)
+        labels = ops.pool_labels_hip(m, lab_cat, offs, ok, P)
+        pos_idx, pos_ok, neg_idx, neg_ok = ops.sample_pos_neg_fixed(labels, S, self.positive_fraction)
+        sel, sel_ok = torch.cat([pos_idx, neg_idx], dim=1), torch.cat([pos_ok, neg_ok], dim=1)
+        order = torch.argsort((~sel_ok).to(torch.int8), dim=1, stable=True)[:, :S]
+        sel, sel_ok = sel.gather(1, order), sel_ok.gather(1, order)
+        rois = cands.gather(1, sel[..., None].expand(-1, -1, 4))
+        labs = labels.gather(1, sel)
+        reg = ops.encode_matched_hip(self.box_coder, gt_cat, offs, m.gather(1, sel), rois, shared=False)[0]
+        return list(rois), labs.reshape(-1), reg.reshape(-1, 4), sel_ok.reshape(-1)
 
     batched = True      # False: the per-image form below (the checker of tests/test_detector_ops.py)
 

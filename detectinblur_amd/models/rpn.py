@@ -184,7 +184,10 @@ class RegionProposalNetwork(nn.Module):
         counts = [l[0].numel() for l in logits]
         objectness, deltas = _flatten_levels(logits, deltas)
         N = feats[0].shape[0]
-        proposals = self.box_coder.decode(deltas.detach(), torch.cat([anchors] * N)).view(N, -1, 4)
+        if ops.hip_boxes_ok(deltas, anchors):
+            proposals = ops.decode_boxes_hip(self.box_coder, deltas.detach(), anchors).view(N, -1, 4)
+        else:
+            proposals = self.box_coder.decode(deltas.detach(), torch.cat([anchors] * N)).view(N, -1, 4)
         return self._filter(proposals, objectness, sizes, counts)
 
     def assign_targets(self, anchors, targets):
@@ -195,6 +198,12 @@ class RegionProposalNetwork(nn.Module):
         if not same or not targets:
             return self.assign_targets_per_image(anchors, targets)
         a = anchors[0]
+        if ops.hip_boxes_ok(a, *[t["boxes"] for t in targets]) and max(t["boxes"].shape[0] for t in targets) <= 256 and len(targets) <= 32:
+            # CUDA: IoU + Matcher in two launches, labels in three, matched boxes in one (csrc/dib_detect.hip)
+            gt_cat, offs = ops.cat_boxes([t["boxes"] for t in targets])
+            m = ops.match_boxes_hip(self.matcher, gt_cat, offs, a, shared=True)
+            lab = (m.clamp(max=0) + 1).to(torch.float32)                      # >= 0 -> 1, BELOW_LOW (-1) -> 0, BETWEEN (-2) -> -1
+            return lab, ops.encode_matched_hip(self.box_coder, gt_cat, offs, m, a, True, want_targets=False, want_matched=True)[1]
         gt, valid = ops.pad_boxes([t["boxes"] for t in targets])
         m = ops.match_batched(self.matcher, ops.box_iou_batched(gt, a), valid)                  # [N, A]
         matched = gt.gather(1, m.clamp(min=0)[..., None].expand(-1, -1, 4))                   # images without boxes: zeros
@@ -202,6 +211,18 @@ class RegionProposalNetwork(nn.Module):
         lab = torch.where(m == ops.Matcher.BELOW_LOW, lab.new_zeros(()), lab)
         lab = torch.where(m == ops.Matcher.BETWEEN, lab.new_full((), -1.0), lab)               # ignored by the sampler
         return lab, matched
+
+    def assign_and_encode(self, anchors, targets):
+        """(labels [N, A], regression targets [N, A, 4]) for the loss."""
+        a = anchors[0]
+        if (all(x is a for x in anchors) and targets and ops.hip_boxes_ok(a, *[t["boxes"] for t in targets])
+                and max(t["boxes"].shape[0] for t in targets) <= 256 and len(targets) <= 32):
+            gt_cat, offs = ops.cat_boxes([t["boxes"] for t in targets])
+            m = ops.match_boxes_hip(self.matcher, gt_cat, offs, a, shared=True)
+            lab = (m.clamp(max=0) + 1).to(torch.float32)
+            return lab, ops.encode_matched_hip(self.box_coder, gt_cat, offs, m, a, True)[0]
+        labels, matched = self.assign_targets(anchors, targets)
+        return labels, self.box_coder.encode(matched.reshape(-1, 4), torch.cat(anchors)).view(len(anchors), -1, 4)
 
     def assign_targets_per_image(self, anchors, targets):
         labels, matched = [], []
@@ -242,13 +263,15 @@ class RegionProposalNetwork(nn.Module):
         counts = [l[0].numel() for l in logits]
         objectness, deltas = _flatten_levels(logits, deltas)
         N = len(anchors)
-        proposals = self.box_coder.decode(deltas.detach(), torch.cat(anchors)).view(N, -1, 4)
+        if all(a is anchors[0] for a in anchors) and ops.hip_boxes_ok(deltas, anchors[0]):
+            proposals = ops.decode_boxes_hip(self.box_coder, deltas.detach(), anchors[0]).view(N, -1, 4)      # one launch
+        else:
+            proposals = self.box_coder.decode(deltas.detach(), torch.cat(anchors)).view(N, -1, 4)
         boxes, _ = self.filter_proposals(proposals, objectness, images.image_sizes, counts, padded=self.training)
         losses = {}
         if self.training:
             assert targets is not None
-            labels, matched = self.assign_targets(anchors, targets)                          # [N, A], [N, A, 4]
-            reg_targets = self.box_coder.encode(matched.reshape(-1, 4), torch.cat(anchors)).view(N, -1, 4)
+            labels, reg_targets = self.assign_and_encode(anchors, targets)                   # [N, A], [N, A, 4]
             obj, box = self.compute_loss(objectness, deltas, labels, reg_targets)
             losses = {"loss_objectness": obj, "loss_rpn_box_reg": box}
         return boxes, losses

@@ -135,6 +135,7 @@ def build_parser():
     p.add_argument("--epochs", default=37, type=int, metavar="N", help="number of total epochs to run")
     p.add_argument("--momentum", default=0.9, type=float, metavar="M", help="momentum")
     p.add_argument("--weight_decay", default=1e-4, type=float, metavar="W", help="weight decay (default: 1e-4)")
+    p.add_argument("--foreach_sgd", action="store_true", help="torch's default (foreach) SGD kernels instead of the fused ones (utils.make_sgd)")
     p.add_argument("--start_from_weights", default=None, help="start training from provided weights")
     p.add_argument("--start_epoch", default=0, type=int, help="Custom start epoch.")
     p.add_argument("--eval_first", action="store_true", help="Evaluate first before training.")
@@ -221,7 +222,7 @@ def main(args):
                                                           broadcast_buffers=False, gradient_as_bucket_view=True)
         model_without_ddp = model.module
     params = [p for p in model.parameters() if p.requires_grad]
-    optimizer = torch.optim.SGD(params, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    optimizer = utils.make_sgd(params, args.lr, args.momentum, args.weight_decay, foreach=args.foreach_sgd)
     lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=args.lr_steps, gamma=args.lr_gamma)
 
     if args.resume:                                                     # reference train.py:251-257

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad, dib_fold_bn_multi, dib_scale_rows_multi; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad, dib_fold_bn_multi, dib_scale_rows_multi, dib_box_match / _encode_matched / _decode, the large LDS window; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -221,6 +221,35 @@ int dib_nms(const float *boxes_sorted_dev, int n, float iou_threshold, void *wor
 int dib_nms_batched(const float *boxes_sorted_dev, const unsigned char *valid_dev, int B, int n,
                     float iou_threshold, void *workspace_dev, long long *keep_dev, int *count_dev,
                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Box bookkeeping of the training step (torchvision's box_iou + Matcher + BoxCoder as the reference's RPN / RoIHeads use
+ * them, models/faster_rcnn.py:150-159, 198-229) for a whole batch per launch.  Ground truth is ragged: gt_cat_dev holds every
+ * image's boxes back to back ([T][4] xyxy), gt_offset (HOST, N + 1 ints) where each image's boxes start; at most 32 images, at
+ * most 256 boxes per image.  Candidates (anchors / proposals): cand_dev [N][M][4], or [M][4] shared by every image
+ * (cand_shared != 0).  Same operations in the same order as the tensor expressions (IoU thresholds fall the same way).
+ *   dib_box_match: match_dev [N][M] int64 = index (inside the image's list) of the ground truth of highest IoU, lowest index
+ *     on ties; -1 where that IoU < low, -2 where low <= IoU < high; with allow_low_quality every candidate that realises some
+ *     ground truth's best IoU keeps its index (best_dev: workspace of T unsigned).  Images without ground truth: -1.
+ *   dib_box_encode_matched: targets_dev [N][M][4] = BoxCoder(weights).encode(gt[max(match, 0)], candidate) and / or
+ *     matched_dev [N][M][4] = that ground-truth box (a zero box for images without ground truth); either may be NULL.
+ *   dib_box_decode: out [R][4] = BoxCoder.decode(deltas [R][4], anchors [A][4]), row r against anchor r % A,
+ *     dw / dh clamped at `clip` (log(1000 / 16)).
+ * ------------------------------------------------------------------------------------- */
+int dib_box_match(const float *gt_cat_dev, const int *gt_offset, int N, const float *cand_dev, int M, int cand_shared, float high,
+                  float low, int allow_low_quality, unsigned *best_dev, long long *match_dev, void *stream);
+int dib_box_encode_matched(const float *gt_cat_dev, const int *gt_offset, int N, const long long *match_dev, const float *cand_dev, int M,
+                           int cand_shared, float wx, float wy, float ww, float wh, float *targets_dev, float *matched_dev, void *stream);
+int dib_box_decode(const float *deltas_dev, const float *anchors_dev, long long R, int A, float wx, float wy, float ww, float wh,
+                   float clip, float *out_dev, void *stream);
+/* RoI-head candidate pool: cands[n] = proposals[n] (P rows) ++ the ground truth of image n ++ [0, 0, 1, 1] rows up to P + Gpad
+ * (torchvision RoIHeads.add_gt_proposals with a fixed shape).  cands_dev: [N][P + Gpad][4]. */
+int dib_box_pool(const float *proposals_dev, int P, const float *gt_cat_dev, const int *gt_offset, int N, int Gpad, float *cands_dev, void *stream);
+/* Class per pool row (RoIHeads.assign_targets_to_proposals): gt_labels[match] for match >= 0, 0 for -1, -1 for -2 and for padding
+ * rows (proposal rows whose ok byte is 0 -- ok_dev may be null: all live --, ground-truth rows beyond the image's count).
+ * match_dev / labels_dev: [N][M] int64, M >= P; gt_labels_cat_dev: int64, concatenated like the boxes. */
+int dib_box_labels(const long long *match_dev, const long long *gt_labels_cat_dev, const int *gt_offset, int N, const unsigned char *ok_dev, int P,
+                   int M, long long *labels_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * COCO box IoU: pycocotools' bbIou (reference cocoapi/common/maskApi.c:109-120), the inner loop of the
