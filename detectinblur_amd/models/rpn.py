@@ -153,6 +153,28 @@ class RegionProposalNetwork(nn.Module):
         N, L = proposals.shape[0], len(counts)
         objectness = objectness.detach().reshape(N, -1)
         K = max(min(self._n(self._pre), n) for n in counts)
+        hip = ops.hip_boxes_ok(objectness, proposals, sizes) and K <= 2048 and L <= 16
+        if hip:
+            # per-level top-k + gather + clip + size test: one launch (csrc/dib_topk.hip) for what follows in the else branch
+            lv_scores, boxes, valid = ops.topk_levels_split_hip(objectness, counts, [min(self._n(self._pre), n) for n in counts], K,
+                                                                proposals, sizes, self.min_size)
+        else:
+            lv_scores, boxes, valid = self._select_levels(proposals, objectness, sizes, counts, K)
+        keep, count = ops.nms_sets_sorted(boxes.reshape(N * L, K, 4), valid.reshape(N * L, K), self.nms_thresh)
+        kept = torch.arange(K, device=keep.device)[None, :] < count[:, None]
+        scores = torch.where(kept, lv_scores.reshape(N * L, K).gather(1, keep), lv_scores.new_full((), float("-inf"))).reshape(N, L * K)
+        boxes = boxes.reshape(N * L, K, 4).gather(1, keep[..., None].expand(-1, -1, 4)).reshape(N, L * K, 4)
+        post = min(self._n(self._post), L * K)
+        if hip and post <= 2048:
+            scores, _, boxes, _ = ops.topk_levels_hip(scores, [L * K], [post], post, boxes)
+            return boxes.reshape(N, post, 4), scores.reshape(N, post), count.reshape(N, L).sum(1).clamp(max=post)
+        scores, top = scores.topk(post, dim=1)                               # survivors of all levels in score order
+        boxes = boxes.gather(1, top[..., None].expand(-1, -1, 4))
+        return boxes, scores, count.reshape(N, L).sum(1).clamp(max=post)
+
+    def _select_levels(self, proposals, objectness, sizes, counts, K):
+        """Per-level top-k, clipping and the size test as tensor expressions (CPU tensors; the checker of the HIP launch)."""
+        N, L = proposals.shape[0], len(counts)
         lv_scores = objectness.new_full((N, L, K), float("-inf"))
         lv_boxes = proposals.new_zeros((N, L, K, 4))
         off = 0
@@ -169,14 +191,7 @@ class RegionProposalNetwork(nn.Module):
         y = lv_boxes[..., 1::2].clamp(min=0).minimum(sizes[:, None, None, 1:2])
         boxes = torch.stack((x[..., 0], y[..., 0], x[..., 1], y[..., 1]), dim=-1)                        # clip_boxes_to_image
         valid = real & ((boxes[..., 2] - boxes[..., 0]) >= self.min_size) & ((boxes[..., 3] - boxes[..., 1]) >= self.min_size)
-        keep, count = ops.nms_sets_sorted(boxes.reshape(N * L, K, 4), valid.reshape(N * L, K), self.nms_thresh)
-        kept = torch.arange(K, device=keep.device)[None, :] < count[:, None]
-        scores = torch.where(kept, lv_scores.reshape(N * L, K).gather(1, keep), lv_scores.new_full((), float("-inf"))).reshape(N, L * K)
-        boxes = boxes.reshape(N * L, K, 4).gather(1, keep[..., None].expand(-1, -1, 4)).reshape(N, L * K, 4)
-        post = min(self._n(self._post), L * K)
-        scores, top = scores.topk(post, dim=1)                               # survivors of all levels in score order
-        boxes = boxes.gather(1, top[..., None].expand(-1, -1, 4))
-        return boxes, scores, count.reshape(N, L).sum(1).clamp(max=post)
+        return lv_scores, boxes, valid
 
     def propose_static(self, feats, anchors, sizes):
         """head + decoding + `_filter` on a list of feature maps: the sync-free part of `forward` in inference."""

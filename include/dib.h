@@ -242,6 +242,17 @@ int dib_box_encode_matched(const float *gt_cat_dev, const int *gt_offset, int N,
                            int cand_shared, float wx, float wy, float ww, float wh, float *targets_dev, float *matched_dev, void *stream);
 int dib_box_decode(const float *deltas_dev, const float *anchors_dev, long long R, int A, float wx, float wy, float ww, float wh,
                    float clip, float *out_dev, void *stream);
+/* Sorted top-k of every (image, level) row of scores in one launch (torchvision filter_proposals' per-level torch.topk + gather +
+ * clip_boxes_to_image + the small-box test, reference models/faster_rcnn.py:198-207 sets the counts).  values_dev: [N][row_stride];
+ * level l covers elements level_offset[l] .. level_offset[l + 1] of a row and yields its level_k[l] (<= K <= 2048) highest scores in
+ * descending order -- equal scores in ascending index order, NaN first -- into out_scores_dev [N][L][K] (rows shorter than K end in
+ * -inf), their level-relative indices into out_index_dev (optional).  With boxes_dev ([N][row_stride][4], same indexing): the
+ * winners' boxes into out_boxes_dev [N][L][K][4], clipped to clip_wh_dev[n] = (width, height) when that is given, and
+ * out_valid_dev [N][L][K] = score > -inf and both clipped sides >= min_size.  L <= 16.  (A long row is bound by the one compute unit
+ * that sweeps it: callers split it into consecutive levels and merge the winners with a second call -- the order is the same.) */
+int dib_topk_levels(const float *values_dev, long long row_stride, int N, const int *level_offset, const int *level_k, int L, int K,
+                    const float *boxes_dev, const float *clip_wh_dev, float min_size, float *out_scores_dev, long long *out_index_dev,
+                    float *out_boxes_dev, unsigned char *out_valid_dev, void *stream);
 /* RoI-head candidate pool: cands[n] = proposals[n] (P rows) ++ the ground truth of image n ++ [0, 0, 1, 1] rows up to P + Gpad
  * (torchvision RoIHeads.add_gt_proposals with a fixed shape).  cands_dev: [N][P + Gpad][4]. */
 int dib_box_pool(const float *proposals_dev, int P, const float *gt_cat_dev, const int *gt_offset, int N, int Gpad, float *cands_dev, void *stream);
