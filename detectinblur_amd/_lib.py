@@ -84,6 +84,8 @@ _SIGNATURES = {
     "dib_topk_levels": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_det_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_float] * 9 +
+                           [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dib_box_pool": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, _c_int_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_void_p]),
     "dib_box_labels": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_int_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,

@@ -249,3 +249,85 @@ extern "C" int dib_box_labels(const long long *match_dev, const long long *gt_la
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }
+
+// ---- detections of one image: softmax + per-class box decoding + clipping + score / size tests in one launch --------------------
+// (torchvision RoIHeads.postprocess_detections up to the NMS; reference models/faster_rcnn.py:213-229 sets score_thresh 0.05,
+// nms_thresh 0.5, detections_per_img 100 and the (10, 10, 5, 5) weights).  One wave per RoI, lane l owns classes l and l + 64.
+// The softmax repeats ATen's softmax_warp_forward for <= 128 classes operation by operation (maximum, exp(x - max), the two
+// addends of a lane first, then the xor-butterfly from offset 32 down to 1, exp(..) / sum), so scores land on the same side of the
+// threshold as the eager path's.  Output is class-major: row c - 1 holds class c's score (-inf where the candidate is dropped) and
+// clipped box for every RoI.
+namespace dib {
+
+__global__ __launch_bounds__(256) void det_candidates_kernel(const float *__restrict__ logits, const float4 *__restrict__ deltas,
+                                                            const float4 *__restrict__ rois, int R, int C, float img_h, float img_w, float wx,
+                                                            float wy, float ww, float wh, float clip, float score_thresh, float min_size,
+                                                            float *__restrict__ scores_cm, float4 *__restrict__ boxes_cm,
+                                                            unsigned *__restrict__ stats) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int c0 = lane, c1 = lane + 64;
+  const float x0 = c0 < C ? logits[(size_t)r * C + c0] : -INFINITY, x1 = c1 < C ? logits[(size_t)r * C + c1] : -INFINITY;
+  float m = x0 < x1 ? x1 : x0;                       // (a < b) ? b : a, ATen's Max functor
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const float b = __shfl_xor(m, o, 64); m = m < b ? b : m; }
+  const float e0 = expf(x0 - m), e1 = expf(x1 - m);
+  float s = 0.f;
+  s += e0;
+  s += e1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s = s + __shfl_xor(s, o, 64);
+  const float4 p = rois[r];
+  const float w = p.z - p.x, h = p.w - p.y, cx = p.x + 0.5f * w, cy = p.y + 0.5f * h;
+  int n_valid = 0;
+  float big = 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int c = half ? c1 : c0;
+    if (c >= 1 && c < C) {
+      const float score = (half ? e1 : e0) / s;
+      const float4 d = deltas[(size_t)r * C + c];
+      float dw = d.z * (1.f / ww), dh = d.w * (1.f / wh);
+      dw = dw > clip ? clip : dw; dh = dh > clip ? clip : dh;
+      const float dx = d.x * (1.f / wx), dy = d.y * (1.f / wy);
+      const float pcx = dx * w + cx, pcy = dy * h + cy, pw = expf(dw) * w, ph = expf(dh) * h;
+      float4 b = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+      b.x = b.x < 0.f ? 0.f : b.x; b.x = b.x > img_w ? img_w : b.x;        // clamp(min=0, max=w): NaN stays NaN
+      b.z = b.z < 0.f ? 0.f : b.z; b.z = b.z > img_w ? img_w : b.z;
+      b.y = b.y < 0.f ? 0.f : b.y; b.y = b.y > img_h ? img_h : b.y;
+      b.w = b.w < 0.f ? 0.f : b.w; b.w = b.w > img_h ? img_h : b.w;
+      const bool ok = score > score_thresh && (b.z - b.x) >= min_size && (b.w - b.y) >= min_size;
+      scores_cm[(size_t)(c - 1) * R + r] = ok ? score : -INFINITY;
+      boxes_cm[(size_t)(c - 1) * R + r] = b;
+      if (ok) { ++n_valid; big = fmaxf(big, fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))); }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { n_valid += __shfl_xor(n_valid, o, 64); big = fmaxf(big, __shfl_xor(big, o, 64)); }
+  if (lane == 0 && n_valid) {
+    atomicAdd(stats, (unsigned)n_valid);
+    atomicMax(stats + 1, __float_as_uint(big));       // coordinates are >= 0 after clipping: the bit patterns order like the numbers
+  }
+}
+
+}  // namespace dib
+
+extern "C" int dib_det_candidates(const float *logits_dev, const float *deltas_dev, const float *rois_dev, int R, int C, float img_h, float img_w,
+                                  float wx, float wy, float ww, float wh, float clip, float score_thresh, float min_size, float *scores_cm_dev,
+                                  float *boxes_cm_dev, unsigned *stats_dev, void *stream) {
+  if (R < 0 || C < 2 || C > 128) { set_error("dib_det_candidates: 2..128 classes"); return DIB_EINVAL; }
+  if (!stats_dev) { set_error("dib_det_candidates: null stats"); return DIB_EINVAL; }
+  DIB_HIP_CHECK(hipMemsetAsync(stats_dev, 0, 2 * sizeof(unsigned), (hipStream_t)stream));
+  if (R == 0) return DIB_OK;
+  if (!logits_dev || !deltas_dev || !rois_dev || !scores_cm_dev || !boxes_cm_dev ||
+      ((((uintptr_t)deltas_dev | (uintptr_t)rois_dev | (uintptr_t)boxes_cm_dev)) & 15) != 0) {
+    set_error("dib_det_candidates: null or misaligned pointer");
+    return DIB_EINVAL;
+  }
+  hipLaunchKernelGGL(dib::det_candidates_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits_dev, (const float4 *)deltas_dev,
+                     (const float4 *)rois_dev, R, C, img_h, img_w, wx, wy, ww, wh, clip, score_thresh, min_size, scores_cm_dev,
+                     (float4 *)boxes_cm_dev, stats_dev);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}

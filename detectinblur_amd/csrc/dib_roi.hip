@@ -400,6 +400,12 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const unsigned long lo
 
     const int valid = min(64, n - blk * 64);
     if (valid < 64) rem |= ~0ull << valid;
+    if (rem == ~0ull) {       // nothing of this block is left (padding / flagged invalid / suppressed): uniform, skip the chain
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) cur[k] = nxt[k];
+      dcur = dnxt;
+      continue;
+    }
     // row j's diagonal word only has bits > j, so bit j of `rem` is final when step j reads it
 #pragma unroll
     for (int j = 0; j < 64; ++j) {

@@ -250,6 +250,22 @@ def topk_levels_hip(values, counts, ks, K, boxes=None, clip_wh=None, min_size=0.
     return scores, index, out_boxes, valid
 
 
+def det_candidates_hip(coder, class_logits, box_regression, rois, image_shape, score_thresh, min_size):
+    """One image's detection candidates, class-major, in one launch (csrc/dib_detect.hip: softmax + decode + clip + tests).
+    Returns (scores [C - 1, R] with -inf where dropped, boxes [C - 1, R, 4], stats int32 [2] = (candidates kept, bits of the largest
+    coordinate among them))."""
+    lg, dl, rois = class_logits.contiguous(), box_regression.contiguous(), rois.contiguous()
+    R, C = lg.shape
+    scores = torch.empty((C - 1, R), dtype=torch.float32, device=lg.device)
+    boxes = torch.empty((C - 1, R, 4), dtype=torch.float32, device=lg.device)
+    stats = torch.empty(2, dtype=torch.int32, device=lg.device)
+    wx, wy, ww, wh = coder.weights
+    _lib.check(_lib.lib().dib_det_candidates(lg.data_ptr(), dl.data_ptr(), rois.data_ptr(), R, C, float(image_shape[0]), float(image_shape[1]), float(wx),
+                                             float(wy), float(ww), float(wh), float(coder.clip), float(score_thresh), float(min_size),
+                                             scores.data_ptr(), boxes.data_ptr(), stats.data_ptr(), _lib.stream_of(lg)))
+    return scores, boxes, stats
+
+
 TOPK_SPLIT = 32768      # rows longer than this are selected in pieces (one workgroup sweeps a piece: ~0.8 us per 1000 elements)
 
 

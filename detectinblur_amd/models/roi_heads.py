@@ -177,6 +177,14 @@ class RoIHeads(nn.Module):
     def postprocess_detections(self, class_logits, box_regression, proposals, image_shapes):
         num_classes = class_logits.shape[-1]
         counts = [p.shape[0] for p in proposals]
+        if (ops.hip_boxes_ok(class_logits, box_regression, *proposals) and num_classes <= 128 and max(counts + [0]) <= 2048
+                and self.detections_per_img <= 2048 and (num_classes - 1) * self.detections_per_img <= ops.TOPK_SPLIT):
+            out, start = [], 0
+            for p, shape in zip(proposals, image_shapes):
+                R = p.shape[0]
+                out.append(self._detections_hip(class_logits[start:start + R], box_regression[start:start + R], p, shape))
+                start += R
+            return out
         boxes = self.box_coder.decode(box_regression, torch.cat(proposals)).split(counts, 0)
         scores = F.softmax(class_logits, -1).split(counts, 0)
         out = []
@@ -191,6 +199,37 @@ class RoIHeads(nn.Module):
             keep = ops.batched_nms(b, s, labels, self.nms_thresh)[:self.detections_per_img]
             out.append({"boxes": b[keep], "labels": labels[keep], "scores": s[keep]})
         return out
+
+    _class_ids = {}
+
+    def _detections_hip(self, class_logits, box_regression, rois, shape):
+        """postprocess_detections of one image in ~20 launches and one host synchronisation (the final count): candidates
+        class-major from one kernel, every class's candidates sorted by one top-k launch, ONE batched NMS over the classes as
+        independent sets -- on boxes moved apart by class * (largest coordinate + 1), the arithmetic of torchvision's batched_nms, so
+        the same pairs suppress each other --, and the classes' survivors (at most detections_per_img of each can matter) ranked by
+        a last top-k.  Equal scores come out in (class, rank) order; the tensor form below leaves their order to an unstable sort."""
+        R, C = class_logits.shape
+        dev, D = class_logits.device, self.detections_per_img
+        if R == 0:
+            return {"boxes": class_logits.new_zeros((0, 4)), "labels": torch.zeros((0,), dtype=torch.int64, device=dev), "scores": class_logits.new_zeros((0,))}
+        scores_cm, boxes_cm, stats = ops.det_candidates_hip(self.box_coder, class_logits, box_regression, rois, shape, self.score_thresh, 1e-2)
+        s, _, b, v = ops.topk_levels_hip(scores_cm, [R], [R], R, boxes_cm, None, float("-inf"))          # [C - 1, 1, R]: per class, by score
+        s, b, v = s[:, 0], b[:, 0], v[:, 0]
+        key = (str(dev), C)
+        cls = RoIHeads._class_ids.get(key)
+        if cls is None:
+            cls = RoIHeads._class_ids[key] = torch.arange(1, C, device=dev)
+        offsets = cls.to(torch.float32) * (stats[1:2].view(torch.float32) + 1)                             # batched_nms: idxs * (boxes.max() + 1)
+        keep, count = ops.nms_sets_sorted(b + offsets[:, None, None], v, self.nms_thresh)
+        d = min(D, R)
+        keep = keep[:, :d]
+        kept = torch.arange(d, device=dev)[None, :] < count[:, None]
+        fs = torch.where(kept, s.gather(1, keep), s.new_full((), float("-inf")))
+        fb = b.gather(1, keep[..., None].expand(-1, -1, 4))
+        k = min(D, (C - 1) * d)
+        top_s, top_i, top_b, _ = ops.topk_levels_hip(fs.reshape(1, -1), [(C - 1) * d], [k], k, fb.reshape(1, -1, 4), want_index=True)
+        n = int(count.sum().clamp(max=D))                                                                  # the one synchronisation
+        return {"boxes": top_b[0, 0, :n], "labels": top_i[0, 0, :n] // d + 1, "scores": top_s[0, 0, :n]}
 
     def forward(self, features, proposals, image_shapes, targets=None):
         if self.training:

@@ -253,6 +253,15 @@ int dib_box_decode(const float *deltas_dev, const float *anchors_dev, long long 
 int dib_topk_levels(const float *values_dev, long long row_stride, int N, const int *level_offset, const int *level_k, int L, int K,
                     const float *boxes_dev, const float *clip_wh_dev, float min_size, float *out_scores_dev, long long *out_index_dev,
                     float *out_boxes_dev, unsigned char *out_valid_dev, void *stream);
+/* Detections of one image up to the NMS (torchvision RoIHeads.postprocess_detections; reference models/faster_rcnn.py:213-229): softmax
+ * over the C <= 128 class logits of every RoI (ATen's operation order), per-class box decoding with BoxCoder weights (wx, wy, ww, wh)
+ * and the log(1000 / 16) clip, clipping to the image, the score > score_thresh and side >= min_size tests.  logits_dev [R][C],
+ * deltas_dev [R][4 C], rois_dev [R][4].  Class-major outputs without the background class: scores_cm_dev [C - 1][R] (-inf where the
+ * candidate is dropped), boxes_cm_dev [C - 1][R][4]; stats_dev[0] = number of candidates kept, stats_dev[1] = bit pattern of the
+ * largest coordinate among them (what batched_nms moves the classes apart by). */
+int dib_det_candidates(const float *logits_dev, const float *deltas_dev, const float *rois_dev, int R, int C, float img_h, float img_w, float wx,
+                       float wy, float ww, float wh, float clip, float score_thresh, float min_size, float *scores_cm_dev, float *boxes_cm_dev,
+                       unsigned *stats_dev, void *stream);
 /* RoI-head candidate pool: cands[n] = proposals[n] (P rows) ++ the ground truth of image n ++ [0, 0, 1, 1] rows up to P + Gpad
  * (torchvision RoIHeads.add_gt_proposals with a fixed shape).  cands_dev: [N][P + Gpad][4]. */
 int dib_box_pool(const float *proposals_dev, int P, const float *gt_cat_dev, const int *gt_offset, int N, int Gpad, float *cands_dev, void *stream);

@@ -175,3 +175,63 @@ def test_rpn_and_roi_training_paths_equal_the_tensor_paths(monkeypatch):
         assert a.shape == b.shape and a.dtype == b.dtype
         assert torch.equal(a.nan_to_num(7.0, 8.0, 9.0), b.nan_to_num(7.0, 8.0, 9.0)) if a.is_floating_point() else torch.equal(a, b)
     assert int((out[True][0] == 1).sum()) > 10 and int((out[True][5] > 0).sum()) > 0
+
+
+def _head_outputs(seed, R, C=91, spread=1.5):
+    g = torch.Generator().manual_seed(seed)
+    logits = (torch.randn(R, C, generator=g) * spread).cuda()
+    deltas = (torch.randn(R, 4 * C, generator=g) * torch.tensor([1.0, 1.0, 2.0, 2.0]).repeat(C)).cuda()
+    rois = _boxes(g, R, 1333.0, 800.0).cuda()
+    return logits, deltas, rois
+
+
+def test_det_candidates_equal_softmax_decode_clip_and_tests():
+    """Scores bit-equal to F.softmax (ATen's reduction order repeated), boxes bit-equal to clip(BoxCoder.decode), the same candidates
+    dropped, count and largest coordinate as torch computes them."""
+    import torch.nn.functional as F
+    coder = ops.BoxCoder((10.0, 10.0, 5.0, 5.0))
+    for R, shape in ((1000, (800, 1333)), (37, (480, 640)), (3, (800, 1088))):
+        logits, deltas, rois = _head_outputs(R, R)
+        logits[0, 5] = 30.0                                                              # a saturated row
+        deltas[1, 8:12] = float("nan")                                                   # class 2 of RoI 1: NaN box -> dropped
+        s, b, stats = ops.det_candidates_hip(coder, logits, deltas, rois, shape, 0.05, 1e-2)
+        want_s = F.softmax(logits, -1)[:, 1:].t()
+        want_b = ops.clip_boxes_to_image(coder.decode(deltas, rois), shape)[:, 1:].permute(1, 0, 2)
+        ok = (want_s > 0.05) & ((want_b[..., 2] - want_b[..., 0]) >= 1e-2) & ((want_b[..., 3] - want_b[..., 1]) >= 1e-2)
+        assert torch.equal(s > float("-inf"), ok) and torch.equal(s[ok], want_s[ok])
+        assert torch.equal(b.isnan(), want_b.isnan()) and torch.equal(b.nan_to_num(0.0), want_b.nan_to_num(0.0))
+        assert int(stats[0]) == int(ok.sum()) > 0 and not bool(ok[1, 1])
+        assert float(stats[1:2].view(torch.float32)) == float(want_b[ok].max())
+
+
+@pytest.mark.parametrize("R,spread", [(1000, 1.5), (1000, 4.0), (37, 1.5), (1, 1.5)])
+def test_detections_equal_the_tensor_path(R, spread, monkeypatch):
+    """RoIHeads.postprocess_detections with the kernels (one NMS set per class on boxes moved apart exactly as batched_nms moves
+    them) against the tensor path on the same head outputs: the same detections, scores and labels in the same order."""
+    heads = _detector_parts().roi_heads
+    logits, deltas, rois = _head_outputs(100 + R, R, spread=spread)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "HIP_BOXES", flag)
+        out[flag] = heads.postprocess_detections(logits, deltas, [rois], [(800, 1333)])[0]
+    a, b = out[True], out[False]
+    assert a["labels"].dtype == b["labels"].dtype == torch.int64 and a["boxes"].shape == b["boxes"].shape
+    assert torch.equal(a["scores"], b["scores"]) and torch.equal(a["labels"], b["labels"]) and torch.equal(a["boxes"], b["boxes"])
+    assert a["scores"].numel() == (min(100, a["scores"].numel()) if R > 1 else a["scores"].numel()) and (R < 37 or a["scores"].numel() > 10)
+    assert (a["scores"][:-1] >= a["scores"][1:]).all()
+
+
+def test_detections_two_images_and_none_left(monkeypatch):
+    heads = _detector_parts().roi_heads
+    l1, d1, r1 = _head_outputs(7, 300)
+    l2, d2, r2 = _head_outputs(8, 200)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "HIP_BOXES", flag)
+        out[flag] = heads.postprocess_detections(torch.cat((l1, l2)), torch.cat((d1, d2)), [r1, r2], [(800, 1333), (600, 900)])
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a["scores"], b["scores"]) and torch.equal(a["labels"], b["labels"]) and torch.equal(a["boxes"], b["boxes"])
+    monkeypatch.setattr(ops, "HIP_BOXES", True)
+    heads.score_thresh = 0.999
+    none = heads.postprocess_detections(l1, d1, [r1], [(800, 1333)])[0]
+    assert none["boxes"].shape == (0, 4) and none["scores"].numel() == 0 and none["labels"].dtype == torch.int64
