@@ -16,13 +16,18 @@ class MT19937(ctypes.Structure):
 
 
 _dp = ctypes.POINTER(ctypes.c_double)
+_llp, _ip, _u8p = ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ubyte)
 _SIGNATURES = {
+    "dib_coco_match_image": (ctypes.c_int, [_dp, ctypes.c_int, ctypes.c_int, _llp, _dp, _dp, _llp, _llp, _dp, _llp, ctypes.c_int, ctypes.c_int, _dp,
+                                            ctypes.c_int, _dp, ctypes.c_int, _ip, _ip, _u8p, _u8p, _ip, _ip]),
     "dib_trajectory_fit": (ctypes.c_int, [ctypes.POINTER(MT19937), ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                           ctypes.c_double, _dp, _dp, _dp]),
     "dib_psf_fit": (ctypes.c_int, [_dp, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int, _dp]),
     "dib_psf_center": (ctypes.c_int, [_dp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "dib_rng_uniform": (ctypes.c_double, [ctypes.POINTER(MT19937)]),
     "dib_rng_gauss": (ctypes.c_double, [ctypes.POINTER(MT19937)]),
+    "dib_coco_match": (ctypes.c_int, [_dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_longlong), _dp, _dp, ctypes.c_int, _dp,
+                                      ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_int)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 _lib = None

@@ -81,6 +81,8 @@ _SIGNATURES = {
                                               ctypes.c_void_p, ctypes.c_void_p]),
     "dib_box_decode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "dib_bias_act_transpose": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "dib_topk_levels": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]),

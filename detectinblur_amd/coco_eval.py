@@ -38,6 +38,35 @@ def _iou_cpu(dt, gt, crowd):
     return out
 
 
+class _CatRecord(object):
+    """Matching results of one (image, category): scores [D], dtm / dt_ig [A, T, D] bool, n_gt [A].  Indexing by area range gives
+    the per-range dict the interpreted matcher returns (`rec[a]["dtm"]` is [T, D])."""
+    __slots__ = ("scores", "dtm", "dt_ig", "n_gt")
+
+    def __init__(self, scores, dtm, dt_ig, n_gt):
+        self.scores, self.dtm, self.dt_ig, self.n_gt = scores, dtm, dt_ig, n_gt
+
+    @classmethod
+    def of(cls, x):
+        if isinstance(x, cls):
+            return x
+        return cls(x[0]["scores"], np.stack([r["dtm"] for r in x]), np.stack([r["dt_ig"] for r in x]), np.asarray([r["n_gt"] for r in x]))
+
+    def __len__(self):
+        return len(self.n_gt)
+
+    def __getitem__(self, a):
+        if not 0 <= a < len(self.n_gt):
+            raise IndexError(a)
+        return dict(scores=self.scores, dtm=self.dtm[a], dt_ig=self.dt_ig[a], n_gt=int(self.n_gt[a]))
+
+    def __getstate__(self):
+        return (self.scores, np.ascontiguousarray(self.dtm), np.ascontiguousarray(self.dt_ig), np.ascontiguousarray(self.n_gt))
+
+    def __setstate__(self, st):
+        self.scores, self.dtm, self.dt_ig, self.n_gt = st
+
+
 class CocoBoxEvaluator(object):
     def __init__(self, ground_truth, device=None, cats=None):
         self.device = torch.device(device) if device is not None else None
@@ -83,23 +112,88 @@ class CocoBoxEvaluator(object):
             if img not in self._seen():
                 self.images.append(img)
                 self._seen_set.add(img)
+            self._match_image(img, boxes, scores, labels, g, iou_all)
+
+    def _match_image(self, img, boxes, scores, labels, g, iou_all):
+        """Every category of one image in one native call (csrc/host/dib_host.c: dib_coco_match_image), outside the interpreter
+        lock; `_match_image_py` is the same thing category by category in Python (the checker)."""
+        import ctypes
+        from . import _hostlib
+        h = _hostlib
+        D, G, K, A, T = len(scores), len(g["labels"]), len(self.cats), len(AREA_RNG), len(IOU_THRS)
+        if not hasattr(self, "_cats_arr"):
+            self._cats_arr = np.ascontiguousarray(self.cats, dtype=np.int64)
+        io = np.ascontiguousarray(iou_all, dtype=np.float64)
+        lab = np.ascontiguousarray(labels, dtype=np.int64)
+        sc = np.ascontiguousarray(scores, dtype=np.float64)
+        da = np.ascontiguousarray(boxes[:, 2] * boxes[:, 3], dtype=np.float64)
+        gl, gc, ga = (np.ascontiguousarray(g["labels"], dtype=np.int64), np.ascontiguousarray(g["crowd"], dtype=np.int64),
+                      np.ascontiguousarray(g["area"], dtype=np.float64))
+        order = np.zeros(max(D, 1), dtype=np.int32)
+        start = np.zeros(K + 1, dtype=np.int32)
+        dtm = np.zeros((A, T, max(D, 1)), dtype=np.uint8)
+        dt_ig = np.zeros((A, T, max(D, 1)), dtype=np.uint8)
+        n_gt = np.zeros((max(K, 1), A), dtype=np.int32)
+        n_cat_gt = np.zeros(max(K, 1), dtype=np.int32)
+        ll = lambda a: a.ctypes.data_as(h._llp)
+        rc = h.lib().dib_coco_match_image(h.dptr(io), D, G, ll(lab), h.dptr(sc), h.dptr(da), ll(gl), ll(gc), h.dptr(ga), ll(self._cats_arr), K,
+                                          MAX_DETS[-1], h.dptr(CocoBoxEvaluator._AREA), A, h.dptr(IOU_THRS), T, order.ctypes.data_as(h._ip),
+                                          start.ctypes.data_as(h._ip), dtm.ctypes.data_as(h._u8p), dt_ig.ctypes.data_as(h._u8p),
+                                          n_gt.ctypes.data_as(h._ip), n_cat_gt.ctypes.data_as(h._ip))
+        if rc != 0:
+            raise RuntimeError("dib_coco_match_image failed (%d)" % rc)
+        dtm, dt_ig = dtm.view(bool), dt_ig.view(bool)
+        st = start.tolist()
+        sk = sc[order[:st[K]]]                                   # every category's scores in its own order, one gather
+        cats, res = self.cats, self.results
+        for k in np.nonzero((start[1:] > start[:-1]) | (n_cat_gt[:K] > 0))[0].tolist():       # plain ints and basic slices from here
+            s, e = st[k], st[k + 1]
+            res[(img, cats[k])] = _CatRecord(sk[s:e], dtm[:, :, s:e], dt_ig[:, :, s:e], n_gt[k])
+
+    def _match_image_py(self, img, boxes, scores, labels, g, iou_all):
             for cat in self.cats:
                 di = np.nonzero(labels == cat)[0]
                 gi = np.nonzero(g["labels"] == cat)[0]
                 if di.size == 0 and gi.size == 0:
                     continue
                 di = di[np.argsort(-scores[di], kind="mergesort")][:MAX_DETS[-1]]
-                self.results[(img, cat)] = self._match(iou_all[np.ix_(di, gi)], scores[di], boxes[di, 2] * boxes[di, 3],
-                                                       g["crowd"][gi], g["area"][gi])
+                self.results[(img, cat)] = self._match_py(iou_all[np.ix_(di, gi)], scores[di], boxes[di, 2] * boxes[di, 3],
+                                                          g["crowd"][gi], g["area"][gi])
 
     def _seen(self):
         if not hasattr(self, "_seen_set") or len(self._seen_set) != len(self.images):
             self._seen_set = set(self.images)
         return self._seen_set
 
+    _AREA = np.ascontiguousarray(np.asarray(AREA_RNG, dtype=np.float64))
+
     @staticmethod
     def _match(ious, scores, dt_area, crowd, gt_area):
-        """evaluateImg for the four area ranges: greedy matching per IoU threshold, detections by score."""
+        """evaluateImg for the four area ranges: greedy matching per IoU threshold, detections by score.  The loop nest runs in
+        the native host library (csrc/host/dib_host.c: dib_coco_match -- the same statements; `_match_py` below is the checker,
+        tests/test_coco_eval.py), outside the interpreter lock: engine.evaluate scores on a worker thread while the main thread
+        launches the next image."""
+        import ctypes
+        from . import _hostlib
+        T, D, G, A = len(IOU_THRS), len(scores), len(crowd), len(AREA_RNG)
+        io = np.ascontiguousarray(ious, dtype=np.float64).reshape(D, G) if D and G else np.zeros((D, G))
+        da = np.ascontiguousarray(dt_area, dtype=np.float64)
+        cr = np.ascontiguousarray(crowd, dtype=np.int64)
+        ga = np.ascontiguousarray(gt_area, dtype=np.float64)
+        dtm = np.zeros((A, T, D), dtype=np.uint8)
+        dt_ig = np.zeros((A, T, D), dtype=np.uint8)
+        n_gt = np.zeros(A, dtype=np.int32)
+        u8 = ctypes.POINTER(ctypes.c_ubyte)
+        rc = _hostlib.lib().dib_coco_match(_hostlib.dptr(io), D, G, _hostlib.dptr(da), cr.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+                                           _hostlib.dptr(ga), _hostlib.dptr(CocoBoxEvaluator._AREA), A, _hostlib.dptr(IOU_THRS), T,
+                                           dtm.ctypes.data_as(u8), dt_ig.ctypes.data_as(u8), n_gt.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        if rc != 0:
+            raise RuntimeError("dib_coco_match failed (%d)" % rc)
+        return [dict(scores=scores, dtm=dtm[a].astype(bool), dt_ig=dt_ig[a].astype(bool), n_gt=int(n_gt[a])) for a in range(A)]
+
+    @staticmethod
+    def _match_py(ious, scores, dt_area, crowd, gt_area):
+        """`_match` as the interpreted loop nest (the reference's own form): the checker of the native routine."""
         out = []
         T, D = len(IOU_THRS), len(scores)
         for lo, hi in AREA_RNG:
@@ -139,15 +233,15 @@ class CocoBoxEvaluator(object):
         recall = -np.ones((T, K, A, M))
         for k, cat in enumerate(self.cats):
             for a in range(A):
-                recs = [self.results[(img, cat)][a] for img in self.images if (img, cat) in self.results]
+                recs = [_CatRecord.of(self.results[(img, cat)]) for img in self.images if (img, cat) in self.results]
                 if not recs:
                     continue
                 for m, max_det in enumerate(MAX_DETS):
-                    scores = np.concatenate([r["scores"][:max_det] for r in recs])
+                    scores = np.concatenate([r.scores[:max_det] for r in recs])
                     inds = np.argsort(-scores, kind="mergesort")
-                    dtm = np.concatenate([r["dtm"][:, :max_det] for r in recs], axis=1)[:, inds]
-                    dt_ig = np.concatenate([r["dt_ig"][:, :max_det] for r in recs], axis=1)[:, inds]
-                    npig = sum(r["n_gt"] for r in recs)
+                    dtm = np.concatenate([r.dtm[a][:, :max_det] for r in recs], axis=1)[:, inds]
+                    dt_ig = np.concatenate([r.dt_ig[a][:, :max_det] for r in recs], axis=1)[:, inds]
+                    npig = sum(int(r.n_gt[a]) for r in recs)
                     if npig == 0:
                         continue
                     tps = np.cumsum(dtm & ~dt_ig, axis=1).astype(np.float64)

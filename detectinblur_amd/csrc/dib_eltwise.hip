@@ -472,3 +472,56 @@ extern "C" int dib_scale_rows_multi(const float *const *g, const float *const *s
   DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }
+
+// ---- bias (+ ReLU) with the layout change MIOpen's planar kernels need, in one pass ------------------------------------------------
+// At batch 1 the wide 3x3 convolutions of ResNet layer2-4 run 1.4-1.7x faster through MIOpen's planar (NCHW) kernels than through
+// its channels-last ones (models/backbone.py: _as_planar).  Around each of them eager PyTorch spent four passes: the epilogue of the
+// convolution before (in place, channels-last), a copy to planar, a copy of the result back to channels-last, its epilogue
+// (profiles/r4_trunk_b1_trace.txt: 0.68 ms of copies per image, the strided NHWC -> NCHW copy at 0.6 TB/s).  These are the two
+// middle pairs as one pass each: a 64 x 64 tile transpose through LDS with the bias indexed on the channel axis.
+//   to_planar = 1: in [N][HW][C] -> out [N][C][HW];   to_planar = 0: in [N][C][HW] -> out [N][HW][C].   out = act(in + bias[c])
+namespace dib {
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bias_act_transpose_kernel(const float *__restrict__ in, const float *__restrict__ bias, float *__restrict__ out,
+                                                                int rows, int cols, int bias_on_cols) {
+  // in: [rows][cols] per image, out: [cols][rows]
+  __shared__ float tile[64][65];
+  const size_t img = (size_t)blockIdx.z * rows * cols;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+  const int c = c0 + tx;
+  const float bc = (bias_on_cols && c < cols) ? bias[c] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int r = r0 + ty + 4 * k;
+    if (r < rows && c < cols) {
+      float v = in[img + (size_t)r * cols + c] + (bias_on_cols ? bc : bias[r]);
+      if (RELU) v = fmaxf(v, 0.f);                               // as bias_act_vec4_kernel
+      tile[ty + 4 * k][tx] = v;
+    }
+  }
+  __syncthreads();
+  const int orow = r0 + tx;                                     // output: [cols][rows]: consecutive lanes along `rows`
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int oc = c0 + ty + 4 * k;
+    if (oc < cols && orow < rows) out[img + (size_t)oc * rows + orow] = tile[tx][ty + 4 * k];
+  }
+}
+
+}  // namespace dib
+
+extern "C" int dib_bias_act_transpose(const float *in_dev, const float *bias_dev, float *out_dev, int N, int C, long long HW, int to_planar, int relu,
+                                      void *stream) {
+  if (N < 0 || C <= 0 || HW <= 0 || HW > 0x7fffffffLL) { set_error("dib_bias_act_transpose: bad shape"); return DIB_EINVAL; }
+  if (N == 0) return DIB_OK;
+  if (!in_dev || !bias_dev || !out_dev || in_dev == out_dev) { set_error("dib_bias_act_transpose: null or aliased pointers"); return DIB_EINVAL; }
+  const int rows = to_planar ? (int)HW : C, cols = to_planar ? C : (int)HW;
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64, N);
+  if (grid.y > 65535 || grid.z > 65535) { set_error("dib_bias_act_transpose: tensor too large for one launch"); return DIB_EINVAL; }
+  if (relu) hipLaunchKernelGGL(dib::bias_act_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in_dev, bias_dev, out_dev, rows, cols, to_planar);
+  else hipLaunchKernelGGL(dib::bias_act_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in_dev, bias_dev, out_dev, rows, cols, to_planar);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}

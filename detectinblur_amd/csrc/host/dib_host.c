@@ -221,3 +221,119 @@ int dib_psf_center(double *psf, int canvas, int *offsets_out) {
   __builtin_free(tmp);
   return 0;
 }
+
+/* ---- COCO matching of one (image, category) for every area range and IoU threshold ---------------------------------------
+ * pycocotools COCOeval.evaluateImg (reference cocoapi/PythonAPI/pycocotools/cocoeval.py:235-310), the loop nest the evaluation
+ * spends its host time in (10 thresholds x detections x ground truth x 4 area ranges, in interpreted Python there).  Same
+ * statements in the same order: ground truth sorted "counted first" by a stable sort of the ignore flag (:257), per threshold
+ * and detection the best still-available ground truth at IoU >= min(thr, 1 - 1e-10) with the early stop at the first ignored
+ * one once a counted one matched (:273-296), unmatched detections outside the area range ignored (:298-299).
+ * Called from a worker thread of engine.evaluate through ctypes, which drops the interpreter lock for the call. */
+int dib_coco_match(const double *ious, int D, int G, const double *dt_area, const long long *crowd, const double *gt_area,
+                   const double *area_rng, int A, const double *iou_thrs, int T, unsigned char *dtm_out,
+                   unsigned char *dt_ig_out, int *n_gt_out) {
+  if (D < 0 || G < 0 || A <= 0 || T <= 0 || !area_rng || !iou_thrs || !dtm_out || !dt_ig_out || !n_gt_out) return -1;
+  if ((D > 0 && !dt_area) || (G > 0 && (!crowd || !gt_area)) || (D > 0 && G > 0 && !ious)) return -1;
+  int *order = (int *)__builtin_malloc((size_t)(G > 0 ? G : 1) * sizeof(int));
+  unsigned char *ig = (unsigned char *)__builtin_malloc((size_t)(G > 0 ? G : 1) * 2);
+  unsigned char *gtm = (unsigned char *)__builtin_malloc((size_t)(G > 0 ? G : 1));
+  if (!order || !ig || !gtm) { __builtin_free(order); __builtin_free(ig); __builtin_free(gtm); return -3; }
+  unsigned char *cr = ig + (G > 0 ? G : 1);
+  for (int a = 0; a < A; ++a) {
+    const double lo = area_rng[2 * a], hi = area_rng[2 * a + 1];
+    /* stable partition: counted ground truth first (np.argsort(ignore, kind="mergesort")) */
+    int n = 0, counted = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int g = 0; g < G; ++g) {
+        const int ignored = (crowd[g] != 0) || (gt_area[g] < lo) || (gt_area[g] > hi);
+        if (ignored == pass) { order[n] = g; ig[n] = (unsigned char)ignored; cr[n] = (unsigned char)(crowd[g] != 0); ++n; }
+      }
+    for (int g = 0; g < G; ++g) counted += !ig[g];
+    n_gt_out[a] = counted;
+    unsigned char *dtm = dtm_out + (size_t)a * T * D, *dt_ig = dt_ig_out + (size_t)a * T * D;
+    for (int t = 0; t < T; ++t) {
+      for (int g = 0; g < G; ++g) gtm[g] = 0;
+      const double thr = iou_thrs[t] < 1 - 1e-10 ? iou_thrs[t] : 1 - 1e-10;
+      for (int d = 0; d < D; ++d) {
+        double best = thr;
+        int m = -1;
+        for (int k = 0; k < G; ++k) {
+          if (gtm[k] && !cr[k]) continue;
+          if (m > -1 && !ig[m] && ig[k]) break;
+          const double v = ious[(size_t)d * G + order[k]];
+          if (v < best) continue;
+          best = v;
+          m = k;
+        }
+        dtm[(size_t)t * D + d] = (unsigned char)(m != -1);
+        dt_ig[(size_t)t * D + d] = (unsigned char)(m != -1 ? ig[m] : 0);
+        if (m != -1) gtm[m] = 1;
+      }
+      for (int d = 0; d < D; ++d)
+        if (!dtm[(size_t)t * D + d] && (dt_area[d] < lo || dt_area[d] > hi)) dt_ig[(size_t)t * D + d] = 1;
+    }
+  }
+  __builtin_free(order); __builtin_free(ig); __builtin_free(gtm);
+  return 0;
+}
+
+/* One image, every category: what CocoBoxEvaluator.update does per image (COCOeval.evaluate's loop over catIds calling
+ * evaluateImg, reference cocoeval.py:160-165, with computeIoU's cut to the maxDets[-1] best detections of a category, :178-184).
+ * iou_all: [D][G] (every detection x every ground truth of the image); labels / scores / areas as given.  For category k (cats[k]):
+ * its detections in stable descending-score order, at most max_det of them, are det_order[cat_start[k] .. cat_start[k + 1]);
+ * dtm_out / dt_ig_out [A][T][D] hold their matching results at those positions (positions past cat_start[K] are unused);
+ * n_gt_out [K][A]; gt_count_out [K] = ground truth of the category (a category without detections but with ground truth still
+ * yields a record). */
+int dib_coco_match_image(const double *iou_all, int D, int G, const long long *dt_label, const double *dt_score, const double *dt_area,
+                         const long long *gt_label, const long long *gt_crowd, const double *gt_area, const long long *cats, int K,
+                         int max_det, const double *area_rng, int A, const double *iou_thrs, int T, int *det_order, int *cat_start,
+                         unsigned char *dtm_out, unsigned char *dt_ig_out, int *n_gt_out, int *gt_count_out) {
+  if (D < 0 || G < 0 || K < 0 || A <= 0 || T <= 0 || max_det < 0 || !cat_start || !n_gt_out || !gt_count_out) return -1;
+  if ((D > 0 && (!dt_label || !dt_score || !dt_area || !det_order || !dtm_out || !dt_ig_out)) || (G > 0 && (!gt_label || !gt_crowd || !gt_area))) return -1;
+  if (K > 0 && !cats) return -1;
+  const size_t dn = (size_t)(D > 0 ? D : 1), gn = (size_t)(G > 0 ? G : 1);
+  int *gi = (int *)__builtin_malloc(gn * sizeof(int));
+  double *sub = (double *)__builtin_malloc(dn * gn * sizeof(double));
+  double *da = (double *)__builtin_malloc(dn * sizeof(double)), *ga = (double *)__builtin_malloc(gn * sizeof(double));
+  long long *cr = (long long *)__builtin_malloc(gn * sizeof(long long));
+  unsigned char *m1 = (unsigned char *)__builtin_malloc((size_t)A * T * dn * 2);
+  int rc = 0;
+  if (!gi || !sub || !da || !ga || !cr || !m1) rc = -3;
+  int pos = 0;
+  for (int k = 0; k < K && rc == 0; ++k) {
+    cat_start[k] = pos;
+    int nd = 0, ng = 0;
+    for (int d = 0; d < D; ++d)
+      if (dt_label[d] == cats[k]) {                      /* stable insertion by descending score (np.argsort(-scores, "mergesort")) */
+        int j = pos + nd;
+        while (j > pos && dt_score[det_order[j - 1]] < dt_score[d]) { det_order[j] = det_order[j - 1]; --j; }
+        det_order[j] = d;
+        ++nd;
+      }
+    if (nd > max_det) nd = max_det;
+    for (int g = 0; g < G; ++g)
+      if (gt_label[g] == cats[k]) gi[ng++] = g;
+    gt_count_out[k] = ng;
+    for (int a = 0; a < A; ++a) n_gt_out[(size_t)k * A + a] = 0;
+    if (nd == 0 && ng == 0) continue;
+    for (int i = 0; i < nd; ++i) {
+      const int d = det_order[pos + i];
+      da[i] = dt_area[d];
+      for (int j = 0; j < ng; ++j) sub[(size_t)i * ng + j] = iou_all[(size_t)d * G + gi[j]];
+    }
+    for (int j = 0; j < ng; ++j) { cr[j] = gt_crowd[gi[j]]; ga[j] = gt_area[gi[j]]; }
+    unsigned char *m2 = m1 + (size_t)A * T * dn;
+    rc = dib_coco_match(sub, nd, ng, da, cr, ga, area_rng, A, iou_thrs, T, m1, m2, n_gt_out + (size_t)k * A);
+    if (rc != 0) break;
+    for (int a = 0; a < A; ++a)
+      for (int t = 0; t < T; ++t)
+        for (int i = 0; i < nd; ++i) {
+          dtm_out[((size_t)a * T + t) * D + pos + i] = m1[((size_t)a * T + t) * nd + i];
+          dt_ig_out[((size_t)a * T + t) * D + pos + i] = m2[((size_t)a * T + t) * nd + i];
+        }
+    pos += nd;
+  }
+  if (rc == 0) cat_start[K] = pos;
+  __builtin_free(gi); __builtin_free(sub); __builtin_free(da); __builtin_free(ga); __builtin_free(cr); __builtin_free(m1);
+  return rc;
+}

@@ -492,6 +492,23 @@ def _folded(conv, bn):
     return hit[1], hit[2]
 
 
+def _folded_planar(conv, bn):
+    """`_folded` with the weight also as a planar (contiguous) tensor, for the convolutions inference runs through MIOpen's planar
+    kernels: cached beside the fold and rewritten in place with it (a captured graph keeps reading the same memory)."""
+    weight, shift = _folded(conv, bn)
+    key = conv.__dict__["_dib_fold"][0]
+    hit = conv.__dict__.get("_dib_fold_planar")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            if hit is not None and hit[1].shape == weight.shape and hit[1].device == weight.device:
+                hit[1].copy_(weight)
+                hit = (key, hit[1])
+            else:
+                hit = (key, weight.contiguous().clone() if weight.is_contiguous() else weight.contiguous())
+        conv.__dict__["_dib_fold_planar"] = hit
+    return hit[1], shift
+
+
 def refresh_folded(module):
     """Bring every cached fold under `module` up to date, in place (see _folded).  Returns the number of folds rewritten.
     Cheap when nothing changed: seven attribute reads per convolution."""
@@ -500,6 +517,8 @@ def refresh_folded(module):
         hit = conv.__dict__.get("_dib_fold")
         if hit is not None and hit[0] != _fold_key(conv, bn):
             _folded(conv, bn)
+            if "_dib_fold_planar" in conv.__dict__:
+                _folded_planar(conv, bn)
             n += 1
     return n
 
@@ -566,6 +585,33 @@ def conv_bn(x, conv, bn, relu=False, residual=None):
     return F.relu(y) if relu else y
 
 
+PLANAR_FUSED = True      # inference: the layout changes around planar 3x3 convolutions ride on the neighbouring epilogues
+
+
+def bias_act_transpose(x, bias, relu, to_planar):
+    """act(x + bias) of a channels-last tensor written planar (to_planar) or of a planar tensor written channels-last: one pass
+    (csrc/dib_eltwise.hip) for what bias_act + .contiguous(...) do in two."""
+    from .. import _lib
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device,
+                      memory_format=torch.contiguous_format if to_planar else torch.channels_last)
+    _lib.check(_lib.lib().dib_bias_act_transpose(x.data_ptr(), bias.data_ptr(), out.data_ptr(), N, C, H * W, int(to_planar), int(relu),
+                                                 _lib.stream_of(x)))
+    return out
+
+
+def _planar_middle(y1, t1, conv2, bn2):
+    """relu(bn2(conv2(relu(y1 + t1)))) with conv2 through MIOpen's planar kernels and both layout changes fused into the epilogues;
+    None where that does not apply (training, CPU, shapes the channels-last kernels win)."""
+    if not (PLANAR_FUSED and FUSE_EPILOGUE and FOLD_FROZEN_BN and not torch.is_grad_enabled() and isinstance(bn2, FrozenBatchNorm2d)
+            and conv2.bias is None and y1.dtype == torch.float32 and _as_planar(y1, conv2) and conv2.dilation == (1, 1)):
+        return None
+    w2, t2 = _folded_planar(conv2, bn2)
+    p = bias_act_transpose(y1, t1, True, True)
+    y2 = F.conv2d(p, w2, None, conv2.stride, conv2.padding, conv2.dilation, conv2.groups)
+    return bias_act_transpose(y2.contiguous(), t2, True, False)
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -586,6 +632,14 @@ class Bottleneck(nn.Module):
             out, idt = entry
         else:
             idt = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
+            mid = None
+            if (PLANAR_FUSED and not torch.is_grad_enabled() and FOLD_FROZEN_BN and isinstance(self.bn1, FrozenBatchNorm2d)
+                    and self.conv1.bias is None and x.is_cuda):
+                w1, t1 = _folded(self.conv1, self.bn1)
+                y1 = conv1x1(x, w1, None, self.conv1)
+                mid = _planar_middle(y1, t1, self.conv2, self.bn2)
+                out = mid if mid is not None else conv_bn(bias_act(y1, t1, None, True), self.conv2, self.bn2, relu=True)
+                return conv_bn(out, self.conv3, self.bn3, relu=True, residual=idt)
             out = conv_bn(x, self.conv1, self.bn1, relu=True)
         out = conv_bn(out, self.conv2, self.bn2, relu=True)
         return conv_bn(out, self.conv3, self.bn3, relu=True, residual=idt)

@@ -242,6 +242,11 @@ int dib_box_encode_matched(const float *gt_cat_dev, const int *gt_offset, int N,
                            int cand_shared, float wx, float wy, float ww, float wh, float *targets_dev, float *matched_dev, void *stream);
 int dib_box_decode(const float *deltas_dev, const float *anchors_dev, long long R, int A, float wx, float wy, float ww, float wh,
                    float clip, float *out_dev, void *stream);
+/* act(in + bias[c]) with the layout change between channels-last and planar in the same pass (inference: around the 3x3
+ * convolutions that run through MIOpen's planar kernels).  to_planar = 1: in [N][HW][C] -> out [N][C][HW]; 0: in [N][C][HW] ->
+ * out [N][HW][C].  Values identical to dib_bias_act_nhwc followed by a copy.  in_dev and out_dev must not alias. */
+int dib_bias_act_transpose(const float *in_dev, const float *bias_dev, float *out_dev, int N, int C, long long HW, int to_planar, int relu,
+                           void *stream);
 /* Sorted top-k of every (image, level) row of scores in one launch (torchvision filter_proposals' per-level torch.topk + gather +
  * clip_boxes_to_image + the small-box test, reference models/faster_rcnn.py:198-207 sets the counts).  values_dev: [N][row_stride];
  * level l covers elements level_offset[l] .. level_offset[l + 1] of a row and yields its level_k[l] (<= K <= 2048) highest scores in

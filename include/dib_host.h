@@ -46,6 +46,24 @@ int dib_psf_center(double *psf, int canvas, int *offsets_out);
 double dib_rng_uniform(dib_mt19937 *rng);
 double dib_rng_gauss(dib_mt19937 *rng);
 
+/* COCO matching of one (image, category): pycocotools COCOeval.evaluateImg (reference cocoapi/PythonAPI/pycocotools/cocoeval.py:
+ * 235-310) for A area ranges x T IoU thresholds in one call.  ious: [D][G] float64, detections (already sorted by descending score
+ * and cut to maxDets) x ground truth of the category; dt_area [D]; crowd [G] (nonzero = iscrowd / ignore), gt_area [G];
+ * area_rng [A][2]; iou_thrs [T].  Outputs: dtm_out / dt_ig_out [A][T][D] bytes (detection matched / ignored), n_gt_out [A] =
+ * ground truth counted in the range.  Returns 0, -1 on bad arguments, -3 out of memory. */
+int dib_coco_match(const double *ious, int D, int G, const double *dt_area, const long long *crowd, const double *gt_area,
+                   const double *area_rng, int A, const double *iou_thrs, int T, unsigned char *dtm_out,
+                   unsigned char *dt_ig_out, int *n_gt_out);
+
+/* One image, every category (COCOeval.evaluate's loop over catIds around evaluateImg, reference cocoeval.py:160-184): iou_all
+ * [D][G] = every detection x every ground truth of the image.  Category cats[k]'s detections in stable descending-score order, at
+ * most max_det of them, are det_order[cat_start[k] .. cat_start[k + 1]) (indices into the D detections); dtm_out / dt_ig_out
+ * [A][T][D] hold their results at those positions; n_gt_out [K][A]; gt_count_out [K] = the category's ground truth in the image. */
+int dib_coco_match_image(const double *iou_all, int D, int G, const long long *dt_label, const double *dt_score, const double *dt_area,
+                         const long long *gt_label, const long long *gt_crowd, const double *gt_area, const long long *cats, int K,
+                         int max_det, const double *area_rng, int A, const double *iou_thrs, int T, int *det_order, int *cat_start,
+                         unsigned char *dtm_out, unsigned char *dt_ig_out, int *n_gt_out, int *gt_count_out);
+
 #ifdef __cplusplus
 }
 #endif

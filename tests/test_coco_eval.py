@@ -56,3 +56,36 @@ def test_evaluator_on_gpu_matches_reference_cocoeval(golden):
     ev, stats = _run("cuda")
     assert np.array_equal(ev.precision, golden.coco["coco_precision"])
     assert np.allclose(stats, golden.coco["coco_stats"], rtol=0, atol=1e-15)
+
+
+def test_native_matching_equals_the_interpreted_loop_nest():
+    """dib_coco_match / dib_coco_match_image (csrc/host/dib_host.c) against the loop nest in Python they restate (pycocotools
+    evaluateImg, reference cocoapi/PythonAPI/pycocotools/cocoeval.py:235-310): random detections and ground truth with crowds, exact
+    hits, IoUs on the thresholds, equal scores, more than maxDets detections of one category, categories with only ground truth or
+    only detections, empty images."""
+    from detectinblur_amd.coco_eval import CocoBoxEvaluator as E
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        D, G = int(rng.integers(0, 260)), int(rng.integers(0, 25))
+        cats = [1, 2, 3, 5, 8, 13, 90]
+        boxes = np.concatenate((rng.random((D, 2)) * 300, 5 + rng.random((D, 2)) * 150), axis=1)
+        scores = np.round(rng.random(D) * 50) / 50 if trial % 2 else rng.random(D)
+        labels = rng.choice(cats[:3] if trial % 4 == 0 else cats, size=D)
+        g = dict(labels=rng.choice(cats, size=G), crowd=(rng.random(G) < 0.2).astype(np.int64), area=rng.random(G) * 30000,
+                 boxes=np.zeros((G, 4)))
+        iou_all = np.round(rng.random((D, G)) * 20) / 20 if trial % 3 == 0 else rng.random((D, G))
+        ev_c, ev_py = E({}, cats=cats), E({}, cats=cats)
+        ev_c._match_image(7, boxes, scores, labels, g, iou_all)
+        ev_py._match_image_py(7, boxes, scores, labels, g, iou_all)
+        assert set(ev_c.results) == set(ev_py.results)
+        for key, recs in ev_py.results.items():
+            for x, y in zip(ev_c.results[key], recs):
+                assert x["n_gt"] == y["n_gt"] and np.array_equal(x["scores"], y["scores"])
+                assert x["dtm"].dtype == bool and np.array_equal(x["dtm"], y["dtm"]) and np.array_equal(x["dt_ig"], y["dt_ig"])
+    # and the per-category routine on its own
+    for trial in range(200):
+        D, G = int(rng.integers(0, 40)), int(rng.integers(0, 12))
+        ious = np.round(rng.random((D, G)) * 20) / 20 if trial % 2 else rng.random((D, G))
+        args = (ious, np.sort(rng.random(D))[::-1].copy(), rng.random(D) * 20000, (rng.random(G) < 0.3).astype(np.int64), rng.random(G) * 20000)
+        for x, y in zip(E._match(*args), E._match_py(*args)):
+            assert x["n_gt"] == y["n_gt"] and np.array_equal(x["dtm"], y["dtm"]) and np.array_equal(x["dt_ig"], y["dt_ig"])
