@@ -41,3 +41,25 @@ if not _os.environ.get("DIB_NO_MIOPEN_DB") and "MIOPEN_USER_DB_PATH" not in _os.
                     _shutil.copy(_os.path.join(_db, _f), _tmp)
             _os.environ["MIOPEN_USER_DB_PATH"] = _tmp
             _atexit.register(_shutil.rmtree, _tmp, True)
+
+# GEMMs (the 1x1 convolutions that run as GEMMs, the box head, the RPN predictor): PyTorch's TunableOp picks, per GEMM shape, the
+# fastest of hipBLASLt's and rocBLAS's solutions instead of the libraries' heuristic default -- at batch 1 the trunk's small GEMMs
+# (M = 1,050 .. 67,200 rows) run 1.3-2x faster that way (trunk replay 6.36 -> 5.71 ms, scratch/t_tunable.sh).  `tunableop/` ships the
+# recorded choices for the shapes of the bench, the drivers at 800 x 1333 / 800 x 1088 and the train step at b = 8
+# (scratch/fill_tunableop.sh regenerates it); like the find-db above the process reads a PRIVATE COPY, with tuning off: a shape
+# that is not in the file runs on the default solution, nothing is measured at run time, every process makes the same choice.
+# The file's validator lines (PyTorch / ROCm / hipBLASLt / rocBLAS versions, gfx950) make PyTorch ignore it on any other stack.
+# An explicit PYTORCH_TUNABLEOP_ENABLED (either value) is respected; DIB_NO_TUNABLEOP=1 opts out.  Must run before the first GEMM.
+if not _os.environ.get("DIB_NO_TUNABLEOP") and "PYTORCH_TUNABLEOP_ENABLED" not in _os.environ:
+    _csv = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tunableop", "tunableop_results.csv")
+    if _os.path.isfile(_csv):
+        import atexit as _atexit
+        import shutil as _shutil
+        import tempfile as _tempfile
+        _tdir = _tempfile.mkdtemp(prefix="dib_tunableop_")
+        for _ordinal in range(16):                   # PyTorch inserts the device ordinal before the extension
+            _shutil.copy(_csv, _os.path.join(_tdir, "tunableop_results%d.csv" % _ordinal))
+        _os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+        _os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
+        _os.environ["PYTORCH_TUNABLEOP_FILENAME"] = _os.path.join(_tdir, "tunableop_results.csv")
+        _atexit.register(_shutil.rmtree, _tdir, True)

@@ -95,3 +95,30 @@ def test_every_process_gets_a_private_copy_of_the_shipped_miopen_find_db():
     assert run({"DIB_NO_MIOPEN_DB": "1"})[0] == "None"
     lines = sum(1 for _ in open(os.path.join(shipped, files[0])))
     assert lines >= 500       # the bench's, the drivers' and the tests' shapes (scratch/fill_miopen_db.sh), not only the b = 8 training ones
+
+
+def test_every_process_reads_a_private_copy_of_the_shipped_gemm_choices():
+    """`import detectinblur_amd` switches PyTorch's TunableOp to look-up-only mode on a temporary copy of
+    detectinblur_amd/tunableop/tunableop_results.csv (one per device ordinal, as PyTorch names them), respects an explicit
+    PYTORCH_TUNABLEOP_ENABLED and DIB_NO_TUNABLEOP, and the shipped file carries the validators PyTorch checks before using it."""
+    import subprocess
+    import sys
+    code = ("import os, detectinblur_amd; e = os.environ; f = e.get('PYTORCH_TUNABLEOP_FILENAME'); "
+            "print(e.get('PYTORCH_TUNABLEOP_ENABLED'), e.get('PYTORCH_TUNABLEOP_TUNING'), f, "
+            "len(os.listdir(os.path.dirname(f))) if f and os.path.isdir(os.path.dirname(f)) else None)")
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("PYTORCH_TUNABLEOP") and k != "DIB_NO_TUNABLEOP"}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.strip().splitlines()[-1].split()
+
+    on, tuning, path, n = run({})
+    assert (on, tuning, n) == ("1", "0", "16") and "dib_tunableop_" in path and not os.path.exists(os.path.dirname(path))
+    assert run({"DIB_NO_TUNABLEOP": "1"})[0] == "None"
+    assert run({"PYTORCH_TUNABLEOP_ENABLED": "0"})[:3] == ["0", "None", "None"]
+    shipped = open(os.path.join(ROOT, "detectinblur_amd", "tunableop", "tunableop_results.csv")).read().splitlines()
+    validators = {l.split(",")[1] for l in shipped if l.startswith("Validator,")}
+    assert {"PT_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"} <= validators
+    assert any("gfx950" in l for l in shipped) and sum(1 for l in shipped if l.startswith("Gemm")) >= 60
