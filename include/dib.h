@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad, dib_fold_bn_multi, dib_scale_rows_multi, dib_box_match / _encode_matched / _decode, the large LDS window; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad, dib_fold_bn_multi, dib_scale_rows_multi, dib_box_match / _encode_matched / _decode / _pool / _labels, dib_topk_levels, dib_det_candidates, dib_bias_act_transpose, the large LDS window; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
