@@ -817,3 +817,14 @@ def test_fold_all_equals_the_per_convolution_folds_bit_for_bit():
         assert float((a - b).norm()) <= 1e-5 * float(b.norm())                      # same folded weights; MIOpen's own run-to-run noise
     assert float((res[True][1] - res[False][1]).norm()) <= 1e-4 * float(res[False][1].norm())
 
+
+
+def test_cat_boxes_offsets_and_alignment():
+    from detectinblur_amd.models import detector_ops as ops
+    a, b, c = torch.rand(3, 4), torch.zeros((0, 4)), torch.rand(2, 4)
+    cat, offs = ops.cat_boxes([a, b, c])
+    assert offs == [0, 3, 3, 5] and torch.equal(cat, torch.cat((a, c)))
+    assert ops.cat_boxes([b, b]) == (None, [0, 0, 0])
+    one, offs = ops.cat_boxes([b, c])
+    assert offs == [0, 0, 2] and torch.equal(one, c)
+    assert not ops.hip_boxes_ok(a)                                # CPU tensors keep the tensor expressions
