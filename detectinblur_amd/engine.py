@@ -105,16 +105,21 @@ def _stage(images_CPU, targets, blur_dicts, device, blurring, want_tables, cuda)
 
 
 class _StagedAhead(object):
-    """Iterates (batch, staged batch) over a loader, one batch ahead: `stage_next()` pulls the next batch from the loader and
-    queues its upload on the side stream (`_to_device(defer=True)`); the iterator hands it out on the following turn.  Batches
-    are consumed in loader order; on the CPU staging is the plain conversion."""
+    """The evaluation loop's look-ahead.  Iterates (batch, prepared) over a loader in loader order; `advance()`, called by the loop
+    just before it launches the detector on the current batch, (1) runs `prepare` -- everything of the NEXT batch that needs no
+    host synchronisation: blur, box growth, float conversion, the blur estimator -- so that work is queued on the GPU before the
+    host blocks on the current detections, and (2) pulls the batch after that from the loader and queues its upload on the side
+    stream (`_to_device(defer=True)`), an iteration before its `prepare` will wait for it.  `prepare(batch, staged)` gets the staged
+    tuple of `_to_device` (adopted by the main stream already); `may_prepare` False keeps (1) inline with the iteration (host
+    random draws in `prepare`, the CPU)."""
 
-    def __init__(self, loader, device, blurring, want_tables):
+    def __init__(self, loader, device, blurring, want_tables, prepare, may_prepare=True):
         self.it, self.device, self.blurring, self.want_tables = iter(loader), device, blurring, want_tables
-        self.pending, self.exhausted = None, False
+        self.prepare, self.may_prepare = prepare, may_prepare and device.type == "cuda"
+        self.staged, self.prepared, self.exhausted = [], None, False
 
-    def stage_next(self):
-        if self.pending is not None or self.exhausted:
+    def _pull(self):
+        if self.exhausted:
             return
         try:
             batch = next(self.it)
@@ -122,15 +127,36 @@ class _StagedAhead(object):
             self.exhausted = True
             return
         images_CPU, targets_CPU, blur_dicts = batch
-        self.pending = (batch, _to_device(images_CPU, targets_CPU, blur_dicts, self.device, self.blurring, want_tables=self.want_tables,
-                                          defer=self.device.type == "cuda"))
+        self.staged.append((batch, _to_device(images_CPU, targets_CPU, blur_dicts, self.device, self.blurring, want_tables=self.want_tables,
+                                              defer=self.device.type == "cuda")))
+
+    def _prepare_first(self):
+        batch, staged = self.staged.pop(0)
+        if self.device.type == "cuda":
+            staged = _adopt(*staged, self.device)
+        return batch, self.prepare(batch, staged)
+
+    def advance(self, more=True):
+        """`more` False: the loop will stop after the current batch (early_stop): nothing further is prepared."""
+        if not more:
+            return
+        if not self.staged:
+            self._pull()
+        if self.may_prepare and self.prepared is None and self.staged:
+            self.prepared = self._prepare_first()
+        if len(self.staged) < 1:
+            self._pull()
 
     def __iter__(self):
         while True:
-            self.stage_next()
-            if self.pending is None:
-                return
-            cur, self.pending = self.pending, None
+            if self.prepared is not None:
+                cur, self.prepared = self.prepared, None
+            else:
+                if not self.staged:
+                    self._pull()
+                if not self.staged:
+                    return
+                cur = self._prepare_first()
             yield cur
 
 
@@ -146,10 +172,14 @@ def _estimate(blur_estimator, x, graphed):
         cache = core.__dict__["_dib_graphs"] = GraphCache(blur_estimator)
     # the graphs read the estimator's parameters and statistics through their live pointers (in-place updates are seen);
     # storage that was REPLACED since the capture (.to(), .half()) leaves them dangling: start over
-    ptrs = tuple(t.data_ptr() for t in core.parameters()) + tuple(t.data_ptr() for t in core.buffers())
+    tensors = core.__dict__.get("_dib_graph_tensors")
+    if tensors is None:                  # walking the module tree costs 0.35 ms per call: the list is kept, the pointers are compared
+        tensors = core.__dict__["_dib_graph_tensors"] = list(core.parameters()) + list(core.buffers())
+    ptrs = tuple(t.data_ptr() for t in tensors)
     if core.__dict__.get("_dib_graph_ptrs") != ptrs:
         if "_dib_graph_ptrs" in core.__dict__:
             cache.clear()
+            core.__dict__.pop("_dib_graph_tensors")      # parameters may have been re-registered
         core.__dict__["_dib_graph_ptrs"] = ptrs
     return cache(x).clone()
 
@@ -384,20 +414,32 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
             with torch.cuda.stream(score_stream):
                 coco_evaluator.update(res)
     try:
-        # On a GPU the NEXT batch is staged (host-to-device copy of the image, PSFs, tap tables: ~0.5 ms at 800 x 1333) on the side
-        # stream while the detector runs on the current one: `ahead.stage_next()` just before the detector is launched.
-        ahead = _StagedAhead(metric_logger.log_every(data_loader, 100, "Test:"), device, blurring_images, gpu_blur or expand_target_boxes)
-        for (images_CPU, targets_CPU, blur_dicts), staged in ahead:
-            if device.type == "cuda":
-                torch.cuda.synchronize()
-            model_time = time.time()
-            images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables = staged if device.type != "cuda" else _adopt(*staged, device)
+        # On a GPU the loop works one batch ahead (_StagedAhead): while the host waits for the detections of image i, image i + 1's
+        # blur, box growth and blur-estimator pass are already queued, and image i + 2's upload runs on the side stream.  Only
+        # work without host random draws goes ahead (--add_noise / --add_block / --add_jpeg_artefacts draw in `blur_image_list`).
+        def prepare(batch, staged):
+            images_CPU, targets_CPU, blur_dicts = batch
+            images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables = staged
             if gpu_blur and blurring_images:
                 blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU=psfs_GPU, add_noise=add_noise, noise_level=noise_level,
                                                add_block=add_block, add_jpeg_artifact=add_jpeg_artifact,
                                                jpeg_compressor=jpeg_compressor, tables=tables)
             if expand_target_boxes and blurring_images:
                 targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU, tables=_tables_128(tables))
+            images_GPU = _to_float(images_GPU, ensemble_models[0] if use_ensemble else model, device)
+            est = None
+            if use_ensemble and blur_estimator is not None:                  # reference :354-366 (the routing itself: below)
+                batched, _ = batcher(images_GPU, None)
+                est = _estimate(blur_estimator, batched.tensors, graphed)
+            return images_GPU, targets_GPU, blur_dicts, thetas, l1, l2, est
+
+        ahead = _StagedAhead(metric_logger.log_every(data_loader, 100, "Test:"), device, blurring_images, gpu_blur or expand_target_boxes,
+                             prepare, may_prepare=not (add_noise or add_block or add_jpeg_artifact))
+        for _, (images_GPU, targets_GPU, blur_dicts, thetas, l1, l2, est) in ahead:
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            model_time = time.time()
+            if expand_target_boxes and blurring_images:
                 # the expanded boxes replace the ground truth's, annotation k <- target box k (reference :325-342,
                 # index-wise: where the target dropped a crowd / degenerate annotation the tail keeps its box)
                 for target in targets_GPU:
@@ -411,7 +453,6 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                             faulty_boxes += 1
                         else:
                             print("Faulty " + str(len(anns) - k) + " times over.")
-            images_GPU = _to_float(images_GPU, ensemble_models[0] if use_ensemble else model, device)
             norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 
             if use_ensemble:                                                 # reference :354-366
@@ -419,16 +460,24 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                 if blur_estimator is None:
                     k = get_network_index_to_use_oracle(blur_dicts, idx)
                 else:
-                    batched, _ = batcher(images_GPU, None)
-                    est = _estimate(blur_estimator, batched.tensors, graphed)
                     k = (get_network_index_to_use_blur_estimator_LEHE if LEHE else get_network_index_to_use_blur_estimator)(est, idx)
                 model = ensemble_models[k]
                 routes.append(k)
-            ahead.stage_next()
+            # the look-ahead step runs right after the detector's trunk has been launched (models/generalized_rcnn.py calls the hook
+            # between the graph replay and its first wait); a model without that hook gets it before the call
+            more = early_stop is None or count + 1 <= early_stop
+            core = getattr(model, "module", model)
+            hooked = graphed and getattr(core, "graph_inference", False)
+            if hooked:
+                core.__dict__["_after_trunk_launch"] = lambda: ahead.advance(more=more)
+            else:
+                ahead.advance(more=more)
             if blurring_images:
                 outputs = model(images_GPU, thetas=thetas, lambda1s=l1, lambda2s=l2, newMeans=norm_means, newSTDs=norm_stds)
             else:
                 outputs = model(images_GPU, killWarp=True, newMeans=norm_means, newSTDs=norm_stds)
+            if hooked and core.__dict__.pop("_after_trunk_launch", None) is not None:
+                ahead.advance(more=more)                                      # the forward pass took a path without the hook
             outputs = [{k: v.to("cpu") for k, v in t.items()} for t in outputs]
             model_time = time.time() - model_time
             res = {}

@@ -512,14 +512,26 @@ def _folded_planar(conv, bn):
 def refresh_folded(module):
     """Bring every cached fold under `module` up to date, in place (see _folded).  Returns the number of folds rewritten.
     Cheap when nothing changed: seven attribute reads per convolution."""
+    # fast path (every replay of a captured trunk calls this): tensor versions only grow, so an unchanged sum over the folds'
+    # inputs means no in-place update since the last call; replaced storage is the caller's pointer check
+    # (GeneralizedRCNN._sync_graphs_with_weights) or shows up as a missing cache entry below
+    pairs = _fold_pairs(module)
+    watch = module.__dict__.get("_dib_fold_watch")
+    if watch is None:
+        watch = module.__dict__["_dib_fold_watch"] = [t for conv, bn in pairs
+                                                       for t in (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+    state = (sum(t._version for t in watch), sum(1 for conv, _ in pairs if "_dib_fold" in conv.__dict__))
+    if module.__dict__.get("_dib_fold_state") == state:
+        return 0
     n = 0
-    for conv, bn in _fold_pairs(module):
+    for conv, bn in pairs:
         hit = conv.__dict__.get("_dib_fold")
         if hit is not None and hit[0] != _fold_key(conv, bn):
             _folded(conv, bn)
             if "_dib_fold_planar" in conv.__dict__:
                 _folded_planar(conv, bn)
             n += 1
+    module.__dict__["_dib_fold_state"] = (sum(t._version for t in watch), sum(1 for conv, _ in pairs if "_dib_fold" in conv.__dict__))
     return n
 
 

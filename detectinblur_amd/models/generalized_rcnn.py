@@ -51,6 +51,8 @@ class GeneralizedRCNN(nn.Module):
             if "_trunk_ptrs" in self.__dict__:
                 cache.clear()
                 self.__dict__.pop("_trunk_tensors")         # parameters may have been re-registered
+            for key in ("_dib_fold_watch", "_dib_fold_state"):      # refresh_folded's shortcut watches the old tensors
+                self.backbone.__dict__.pop(key, None)
             self.__dict__["_trunk_ptrs"] = ptrs
         refresh_folded(self.backbone)
 
@@ -68,6 +70,11 @@ class GeneralizedRCNN(nn.Module):
             cache = self.__dict__["_trunk_graphs"] = GraphCache(self._trunk)
         self._sync_graphs_with_weights(cache)
         outs = cache(x)
+        hook = self.__dict__.pop("_after_trunk_launch", None)
+        if hook is not None:
+            # engine.evaluate's look-ahead: the trunk is queued, the host is about to wait for it -- the moment to queue the next
+            # image's blur / estimator pass and the upload of the one after (one call per forward pass, then forgotten)
+            hook()
         features = OrderedDict(zip(self._feat_names, outs[:-4]))
         proposals, _ = self.rpn.unpad(*outs[-4:-1])
         detections, _ = self.roi_heads(features, proposals, images.image_sizes, None)

@@ -156,11 +156,11 @@ def test_ddp_gloo_world_size_2(tmp_path):
 
 
 def test_staged_ahead_hands_out_every_batch_once_in_loader_order():
-    """The evaluation loop's one-batch look-ahead (engine._StagedAhead) on the CPU: every batch exactly once, in order, whether
-    `stage_next` is called early, twice or never; nothing is pulled from the loader before it is asked for."""
+    """The evaluation loop's look-ahead (engine._StagedAhead) on the CPU, where nothing is prepared early: every batch exactly once,
+    in order, prepared exactly once, whether `advance` is called, called twice or never; `advance(more=False)` pulls nothing."""
     import torch
     from detectinblur_amd import engine
-    pulled = []
+    pulled, prepared = [], []
 
     def loader(n):
         for i in range(n):
@@ -168,17 +168,29 @@ def test_staged_ahead_hands_out_every_batch_once_in_loader_order():
             img = torch.full((3, 8, 8), float(i))
             yield [img], [{"boxes": torch.zeros((0, 4)), "image_id": torch.tensor(i)}], [{"blurring": False, "psf": [0]}]
 
-    ahead = engine._StagedAhead(loader(5), torch.device("cpu"), False, False)
+    def prepare(batch, staged):
+        prepared.append(int(batch[0][0][0, 0, 0]))
+        return staged
+
+    ahead = engine._StagedAhead(loader(5), torch.device("cpu"), False, False, prepare)
     seen = []
     for k, ((images, targets, dicts), staged) in enumerate(ahead):
-        assert pulled == list(range(len(seen) + 1)) or pulled == list(range(len(seen) + 2))
         images_dev = staged[0]
         seen.append(int(images[0][0, 0, 0]))
+        assert prepared == seen                                   # the CPU prepares a batch when it hands it out, not before
         assert float(images_dev[0][0, 0, 0]) == seen[-1] and images_dev[0].dtype == torch.float16
         if k % 2 == 0:
-            ahead.stage_next(); ahead.stage_next()            # early and twice: still one batch ahead
-    assert seen == [0, 1, 2, 3, 4] and pulled == [0, 1, 2, 3, 4] and ahead.exhausted
-    assert list(engine._StagedAhead(loader(0), torch.device("cpu"), False, False)) == []
+            ahead.advance(); ahead.advance()                      # early and twice: at most one batch pulled ahead
+        assert len(pulled) <= len(seen) + 1
+    assert seen == prepared == pulled == [0, 1, 2, 3, 4] and ahead.exhausted
+    assert list(engine._StagedAhead(loader(0), torch.device("cpu"), False, False, prepare)) == []
+    pulled.clear(); prepared.clear()
+    ahead = engine._StagedAhead(loader(5), torch.device("cpu"), False, False, prepare)
+    for k, _ in enumerate(ahead):
+        ahead.advance(more=k < 1)                                  # the loop announces its last batch (early_stop)
+        if k == 1:
+            break
+    assert pulled == [0, 1] and prepared == [0, 1]
 
 
 def test_make_sgd_is_torchs_sgd_and_records_pickle():
