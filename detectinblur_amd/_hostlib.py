@@ -18,6 +18,8 @@ class MT19937(ctypes.Structure):
 _dp = ctypes.POINTER(ctypes.c_double)
 _llp, _ip, _u8p = ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ubyte)
 _SIGNATURES = {
+    "dib_coco_accumulate_cat": (ctypes.c_int, [_dp, _ip, ctypes.c_int, _u8p, _u8p, _ip, ctypes.c_int, ctypes.c_int, _ip, ctypes.c_int, _dp,
+                                               ctypes.c_int, _dp, _dp]),
     "dib_coco_match_image": (ctypes.c_int, [_dp, ctypes.c_int, ctypes.c_int, _llp, _dp, _dp, _llp, _llp, _dp, _llp, ctypes.c_int, ctypes.c_int, _dp,
                                             ctypes.c_int, _dp, ctypes.c_int, _ip, _ip, _u8p, _u8p, _ip, _ip]),
     "dib_trajectory_fit": (ctypes.c_int, [ctypes.POINTER(MT19937), ctypes.c_int, ctypes.c_int, ctypes.c_double,

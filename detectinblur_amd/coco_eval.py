@@ -228,6 +228,37 @@ class CocoBoxEvaluator(object):
 
     # ---- accumulate + summarize ---------------------------------------------------------------------------
     def accumulate(self):
+        """COCOeval.accumulate (reference cocoapi/PythonAPI/pycocotools/cocoeval.py:315-420).  Per category the records of all
+        images are laid end to end once and the ranking, the running counts and the 101-point precision curves for every
+        (maxDets, area range, IoU threshold) come from one native call (csrc/host/dib_host.c: dib_coco_accumulate_cat);
+        `accumulate_py` is the interpreted form, the checker."""
+        from . import _hostlib as h
+        T, R, K, A, M = len(IOU_THRS), len(REC_THRS), len(self.cats), len(AREA_RNG), len(MAX_DETS)
+        precision = -np.ones((T, R, K, A, M))
+        recall = -np.ones((T, K, A, M))
+        max_dets = np.asarray(MAX_DETS, dtype=np.int32)
+        rec_thrs = np.ascontiguousarray(REC_THRS, dtype=np.float64)
+        for k, cat in enumerate(self.cats):
+            recs = [_CatRecord.of(self.results[(img, cat)]) for img in self.images if (img, cat) in self.results]
+            if not recs:
+                continue
+            lens = np.asarray([len(r.scores) for r in recs], dtype=np.int32)
+            scores = np.ascontiguousarray(np.concatenate([r.scores for r in recs]), dtype=np.float64)
+            dtm = np.ascontiguousarray(np.concatenate([r.dtm for r in recs], axis=2)).view(np.uint8)
+            dt_ig = np.ascontiguousarray(np.concatenate([r.dt_ig for r in recs], axis=2)).view(np.uint8)
+            n_gt = np.ascontiguousarray(np.sum([r.n_gt for r in recs], axis=0), dtype=np.int32)
+            p_cat, r_cat = -np.ones((A, M, T, R)), -np.ones((A, M, T))
+            rc = h.lib().dib_coco_accumulate_cat(h.dptr(scores), lens.ctypes.data_as(h._ip), len(recs), dtm.ctypes.data_as(h._u8p),
+                                                 dt_ig.ctypes.data_as(h._u8p), n_gt.ctypes.data_as(h._ip), A, T, max_dets.ctypes.data_as(h._ip), M,
+                                                 h.dptr(rec_thrs), R, h.dptr(p_cat), h.dptr(r_cat))
+            if rc != 0:
+                raise RuntimeError("dib_coco_accumulate_cat failed (%d)" % rc)
+            precision[:, :, k, :, :] = p_cat.transpose(2, 3, 0, 1)
+            recall[:, k, :, :] = r_cat.transpose(2, 0, 1)
+        self.precision, self.recall = precision, recall
+        return precision, recall
+
+    def accumulate_py(self):
         T, R, K, A, M = len(IOU_THRS), len(REC_THRS), len(self.cats), len(AREA_RNG), len(MAX_DETS)
         precision = -np.ones((T, R, K, A, M))
         recall = -np.ones((T, K, A, M))

@@ -337,3 +337,72 @@ int dib_coco_match_image(const double *iou_all, int D, int G, const long long *d
   __builtin_free(gi); __builtin_free(sub); __builtin_free(da); __builtin_free(ga); __builtin_free(cr); __builtin_free(m1);
   return rc;
 }
+
+/* ---- COCO accumulate for one category ---------------------------------------------------------------------------------------
+ * pycocotools COCOeval.accumulate (reference cocoapi/PythonAPI/pycocotools/cocoeval.py:315-420) for the records of ONE category:
+ * per maxDets the first max_det detections of every image, all of them ranked by a stable descending sort of the score (:366-372),
+ * per area range and IoU threshold the running true / false positive counts, recall = tp / npig, precision = tp / (fp + tp + eps),
+ * the precision envelope from the right, and the precision at the first position whose recall reaches each recall threshold
+ * (np.searchsorted(rc, recThrs, side="left"); 0 beyond the last) (:381-412).  Inputs are the category's records laid end to end:
+ * scores [n], lens [nrec] (detections per image, summing to n), dtm / dt_ig [A][T][n] bytes, n_gt [A] (counted ground truth).
+ * Outputs, written only where n_gt[a] > 0 (the caller pre-fills -1): precision_out [A][M][T][R], recall_out [A][M][T]. */
+static void merge_sort_desc(int *idx, int *tmp, int n, const double *score) {
+  for (int w = 1; w < n; w *= 2) {
+    for (int lo = 0; lo < n; lo += 2 * w) {
+      int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n, i = lo, j = mid, k = lo;
+      while (i < mid && j < hi) tmp[k++] = (score[idx[j]] > score[idx[i]]) ? idx[j++] : idx[i++];     /* ties: the left (earlier) one first */
+      while (i < mid) tmp[k++] = idx[i++];
+      while (j < hi) tmp[k++] = idx[j++];
+    }
+    for (int i = 0; i < n; ++i) idx[i] = tmp[i];
+  }
+}
+
+int dib_coco_accumulate_cat(const double *scores, const int *lens, int nrec, const unsigned char *dtm, const unsigned char *dt_ig,
+                            const int *n_gt, int A, int T, const int *max_dets, int M, const double *rec_thrs, int R,
+                            double *precision_out, double *recall_out) {
+  if (nrec < 0 || A <= 0 || T <= 0 || M <= 0 || R <= 0 || !n_gt || !max_dets || !rec_thrs || !precision_out || !recall_out) return -1;
+  long long n = 0;
+  for (int i = 0; i < nrec; ++i) { if (lens[i] < 0) return -1; n += lens[i]; }
+  if (n > 0 && (!scores || !dtm || !dt_ig)) return -1;
+  const size_t cap = (size_t)(n > 0 ? n : 1);
+  int *idx = (int *)__builtin_malloc(cap * sizeof(int)), *tmp = (int *)__builtin_malloc(cap * sizeof(int));
+  double *rc = (double *)__builtin_malloc(cap * sizeof(double)), *pr = (double *)__builtin_malloc(cap * sizeof(double));
+  if (!idx || !tmp || !rc || !pr) { __builtin_free(idx); __builtin_free(tmp); __builtin_free(rc); __builtin_free(pr); return -3; }
+  const double eps = 2.220446049250313e-16;                       /* np.spacing(1) */
+  for (int m = 0; m < M; ++m) {
+    int nd = 0;
+    long long off = 0;
+    for (int i = 0; i < nrec; ++i) {
+      const int take = lens[i] < max_dets[m] ? lens[i] : max_dets[m];
+      for (int j = 0; j < take; ++j) idx[nd++] = (int)(off + j);
+      off += lens[i];
+    }
+    merge_sort_desc(idx, tmp, nd, scores);
+    for (int a = 0; a < A; ++a) {
+      if (n_gt[a] == 0) continue;
+      const double npig = (double)n_gt[a];
+      for (int t = 0; t < T; ++t) {
+        const unsigned char *mt = dtm + ((size_t)a * T + t) * (size_t)n, *ig = dt_ig + ((size_t)a * T + t) * (size_t)n;
+        long long tp = 0, fp = 0;
+        for (int i = 0; i < nd; ++i) {
+          const int d = idx[i];
+          if (!ig[d]) { if (mt[d]) ++tp; else ++fp; }
+          rc[i] = (double)tp / npig;
+          pr[i] = (double)tp / (((double)fp + (double)tp) + eps);
+        }
+        recall_out[((size_t)a * M + m) * T + t] = nd ? rc[nd - 1] : 0.0;
+        for (int i = nd - 1; i > 0; --i)
+          if (pr[i] > pr[i - 1]) pr[i - 1] = pr[i];
+        double *q = precision_out + (((size_t)a * M + m) * T + t) * (size_t)R;
+        int pos = 0;
+        for (int r = 0; r < R; ++r) {                               /* rec_thrs ascend, rc is non-decreasing: one forward walk */
+          while (pos < nd && rc[pos] < rec_thrs[r]) ++pos;
+          q[r] = pos < nd ? pr[pos] : 0.0;
+        }
+      }
+    }
+  }
+  __builtin_free(idx); __builtin_free(tmp); __builtin_free(rc); __builtin_free(pr);
+  return 0;
+}

@@ -64,6 +64,13 @@ int dib_coco_match_image(const double *iou_all, int D, int G, const long long *d
                          int max_det, const double *area_rng, int A, const double *iou_thrs, int T, int *det_order, int *cat_start,
                          unsigned char *dtm_out, unsigned char *dt_ig_out, int *n_gt_out, int *gt_count_out);
 
+/* COCOeval.accumulate for the records of one category (reference cocoeval.py:315-420): scores [n] = the images' detections laid
+ * end to end, lens [nrec] detections per image, dtm / dt_ig [A][T][n] bytes, n_gt [A]; max_dets [M]; rec_thrs [R] ascending.
+ * precision_out [A][M][T][R] and recall_out [A][M][T] are written where n_gt[a] > 0 (pre-fill with -1). */
+int dib_coco_accumulate_cat(const double *scores, const int *lens, int nrec, const unsigned char *dtm, const unsigned char *dt_ig,
+                            const int *n_gt, int A, int T, const int *max_dets, int M, const double *rec_thrs, int R,
+                            double *precision_out, double *recall_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,14 @@ import os
 import subprocess
 import sys
 
+
+def _free_port():
+    """a port nobody listens on right now: two test sessions on one machine must not meet on a fixed one"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -46,7 +54,7 @@ def test_under_torchrun_the_driver_form():
     """the driver's own N>1 command line: torch.distributed.run ... bench.py --gpus N"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-gloo"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

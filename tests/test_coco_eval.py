@@ -89,3 +89,28 @@ def test_native_matching_equals_the_interpreted_loop_nest():
         args = (ious, np.sort(rng.random(D))[::-1].copy(), rng.random(D) * 20000, (rng.random(G) < 0.3).astype(np.int64), rng.random(G) * 20000)
         for x, y in zip(E._match(*args), E._match_py(*args)):
             assert x["n_gt"] == y["n_gt"] and np.array_equal(x["dtm"], y["dtm"]) and np.array_equal(x["dt_ig"], y["dt_ig"])
+
+
+def test_native_accumulate_equals_the_interpreted_form():
+    """dib_coco_accumulate_cat against the interpreted accumulate (pycocotools COCOeval.accumulate, reference
+    cocoapi/PythonAPI/pycocotools/cocoeval.py:315-420): equal scores across images (stable ranking), categories without counted
+    ground truth, images with more than maxDets detections, empty categories -- bit-identical precision and recall arrays."""
+    from detectinblur_amd.coco_eval import CocoBoxEvaluator as E
+    rng = np.random.default_rng(3)
+    cats = list(range(1, 31))
+    ev = E({}, cats=cats)
+    for img in range(60):
+        D, G = int(rng.integers(0, 130)), int(rng.integers(0, 10))
+        boxes = np.concatenate((rng.random((D, 2)) * 300, 5 + rng.random((D, 2)) * 150), axis=1)
+        scores = np.round(rng.random(D) * 40) / 40 if img % 2 else rng.random(D)
+        labels = rng.choice(cats[:1] if img % 7 == 0 else (cats[:6] if img % 3 == 0 else cats[:-2]), size=D)
+        g = dict(labels=rng.choice(cats[:-1], size=G), crowd=(rng.random(G) < 0.2).astype(np.int64), area=rng.random(G) * 30000, boxes=np.zeros((G, 4)))
+        ev.images.append(img)
+        ev._match_image(img, boxes, scores, labels, g, np.round(rng.random((D, G)) * 20) / 20)
+    p1, r1 = ev.accumulate()
+    p2, r2 = ev.accumulate_py()
+    assert np.array_equal(p1, p2) and np.array_equal(r1, r2)
+    assert (p1 > -1).sum() > 10000 and (p1[:, :, -1] == -1).all()          # the last category never occurs: untouched
+    s1 = ev.summarize()
+    ev.precision, ev.recall = p2, r2
+    assert np.array_equal(s1, ev.summarize())

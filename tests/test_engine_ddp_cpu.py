@@ -8,6 +8,14 @@ import sys
 import pytest
 import torch
 
+
+def _free_port():
+    """a port nobody listens on right now: two test sessions on one machine must not meet on a fixed one"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -150,7 +158,7 @@ def test_ddp_gloo_world_size_2(tmp_path):
     script.write_text(_DDP_SCRIPT % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29611", str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        "--master-port", str(_free_port()), str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 

@@ -21,7 +21,8 @@ def test_host_library_is_clean_under_asan_and_ubsan():
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_host_native.py"),
                         os.path.join(ROOT, "tests", "test_transforms_cpu.py"),
-                        os.path.join(ROOT, "tests", "test_coco_eval.py") + "::test_native_matching_equals_the_interpreted_loop_nest"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+                        os.path.join(ROOT, "tests", "test_coco_eval.py") + "::test_native_matching_equals_the_interpreted_loop_nest",
+                        os.path.join(ROOT, "tests", "test_coco_eval.py") + "::test_native_accumulate_equals_the_interpreted_form"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = (r.stdout[-3000:] + r.stderr[-3000:])
     assert r.returncode == 0, tail
     assert "passed" in r.stdout and "AddressSanitizer" not in tail and "runtime error" not in tail
