@@ -433,6 +433,30 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                 est = _estimate(blur_estimator, batched.tensors, graphed)
             return images_GPU, targets_GPU, blur_dicts, thetas, l1, l2, est
 
+        def submit(ids, outputs, gt_xywh, started):
+            """detections of one batch (CPU tensors) -> result tables + the evaluator (reference :376-392)"""
+            model_time = time.time() - started
+            res = {}
+            for image_id, o, g in zip(ids, outputs, gt_xywh):
+                res[image_id] = o
+                detections[image_id] = o
+                gt_boxes[image_id] = g
+            evaluator_time = time.time()
+            if scorer is None:
+                coco_evaluator.update(res)                                   # reference :388-392
+            else:
+                pending.append(scorer.submit(score, res))                    # scored while the GPU runs the next image
+            metric_logger.update(model_time=model_time, evaluator_time=time.time() - evaluator_time)
+
+        def finalize(entry):
+            core_, handle_, ids_, gt_, started_ = entry
+            submit(ids_, core_.finish(handle_), gt_, started_)
+
+        # models whose internal warp is on need thetas / lambdas in forward: they stay on the plain loop
+        pipelined = (graphed and not os.environ.get("DIB_NO_PIPELINE")
+                     and not any(getattr(getattr(m, "module", m), "warp_internally", False) and blurring_images
+                                 for m in (ensemble_models if use_ensemble else [model])))
+        trunk_running, in_flight = None, []
         ahead = _StagedAhead(metric_logger.log_every(data_loader, 100, "Test:"), device, blurring_images, gpu_blur or expand_target_boxes,
                              prepare, may_prepare=not (add_noise or add_block or add_jpeg_artifact))
         for _, (images_GPU, targets_GPU, blur_dicts, thetas, l1, l2, est) in ahead:
@@ -463,39 +487,65 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                     k = (get_network_index_to_use_blur_estimator_LEHE if LEHE else get_network_index_to_use_blur_estimator)(est, idx)
                 model = ensemble_models[k]
                 routes.append(k)
-            # the look-ahead step runs right after the detector's trunk has been launched (models/generalized_rcnn.py calls the hook
-            # between the graph replay and its first wait); a model without that hook gets it before the call
             more = early_stop is None or count + 1 <= early_stop
             core = getattr(model, "module", model)
-            hooked = graphed and getattr(core, "graph_inference", False)
-            if hooked:
-                core.__dict__["_after_trunk_launch"] = lambda: ahead.advance(more=more)
-            else:
-                ahead.advance(more=more)
-            if blurring_images:
-                outputs = model(images_GPU, thetas=thetas, lambda1s=l1, lambda2s=l2, newMeans=norm_means, newSTDs=norm_stds)
-            else:
-                outputs = model(images_GPU, killWarp=True, newMeans=norm_means, newSTDs=norm_stds)
-            if hooked and core.__dict__.pop("_after_trunk_launch", None) is not None:
-                ahead.advance(more=more)                                      # the forward pass took a path without the hook
-            outputs = [{k: v.to("cpu") for k, v in t.items()} for t in outputs]
-            model_time = time.time() - model_time
-            res = {}
-            for t, o in zip(targets_GPU, outputs):
-                image_id = int(t["image_id"]) if "image_id" in t else count
-                res[image_id] = o
-                detections[image_id] = o
-                gt_boxes[image_id] = utils.convert_to_xywh(t["boxes"]).cpu()
-            evaluator_time = time.time()
-            if scorer is None:
-                coco_evaluator.update(res)                                   # reference :388-392
-            else:
-                pending.append(scorer.submit(score, res))                    # scored while the GPU runs the next image
-            evaluator_time = time.time() - evaluator_time
-            metric_logger.update(model_time=model_time, evaluator_time=evaluator_time)
+            ids = [int(t["image_id"]) if "image_id" in t else count for t in targets_GPU]
+            handle = None
+            if pipelined and hasattr(core, "launch_trunk"):
+                # Pipelined (GPU, graph inference): the queue is empty here (the synchronisation above).  Queue, in this order and
+                # without waiting for any of it: the RoI heads + detections of the PREVIOUS image (its trunk has finished: reading
+                # its proposal counts costs nothing) with their copy to pinned memory, this image's trunk, the next image's blur /
+                # estimator pass and the upload of the one after; then turn the detections that were copied before the
+                # synchronisation into evaluator updates while the GPU works.  Same tensors through the same kernels as the
+                # plain loop below (tests/test_full_size_gpu.py compares the two).
+                ready, in_flight = in_flight, []
+                if trunk_running is not None:
+                    if trunk_running[0].launch_heads(trunk_running[1]) is None:
+                        raise RuntimeError("evaluate: the detector left the pipelined path between its trunk and its heads")
+                    in_flight.append(trunk_running)
+                    trunk_running = None
+                handle = core.launch_trunk(images_GPU, killWarp=not blurring_images, newMeans=norm_means, newSTDs=norm_stds)
+                if handle is not None:
+                    trunk_running = (core, handle, ids, [utils.convert_to_xywh(t["boxes"]).cpu() for t in targets_GPU], model_time)
+                    ahead.advance(more=more)
+                    for entry in ready:
+                        finalize(entry)
+                else:                                                        # this detector does not take the path: drain, then as below
+                    for entry in ready + in_flight:
+                        torch.cuda.synchronize()
+                        finalize(entry)
+                    in_flight = []
+            if handle is None:
+                # the look-ahead step runs right after the detector's trunk has been launched (models/generalized_rcnn.py calls
+                # the hook between the graph replay and its first wait); a model without that hook gets it before the call
+                hooked = graphed and getattr(core, "graph_inference", False)
+                if hooked:
+                    core.__dict__["_after_trunk_launch"] = lambda: ahead.advance(more=more)
+                else:
+                    ahead.advance(more=more)
+                if blurring_images:
+                    outputs = model(images_GPU, thetas=thetas, lambda1s=l1, lambda2s=l2, newMeans=norm_means, newSTDs=norm_stds)
+                else:
+                    outputs = model(images_GPU, killWarp=True, newMeans=norm_means, newSTDs=norm_stds)
+                if hooked and core.__dict__.pop("_after_trunk_launch", None) is not None:
+                    ahead.advance(more=more)                                  # the forward pass took a path without the hook
+                outputs = [{k: v.to("cpu") for k, v in t.items()} for t in outputs]
+                submit(ids, outputs, [utils.convert_to_xywh(t["boxes"]).cpu() for t in targets_GPU], model_time)
             count += 1
             if early_stop is not None and count > early_stop:
                 break
+        # the pipeline's tail: heads of the last image, then everything that is still on its way
+        if trunk_running is not None:
+            torch.cuda.synchronize()
+            if trunk_running[0].launch_heads(trunk_running[1]) is None:
+                raise RuntimeError("evaluate: the detector left the pipelined path between its trunk and its heads")
+            in_flight.append(trunk_running)
+            trunk_running = None
+        if in_flight:
+            torch.cuda.synchronize()
+            for entry in in_flight:
+                finalize(entry)
+            in_flight = []
     finally:                                                             # also on an error in the loop: no stray thread, thread count restored
         if scorer is not None:
             scorer.shutdown(wait=True)

@@ -80,6 +80,70 @@ class GeneralizedRCNN(nn.Module):
         detections, _ = self.roi_heads(features, proposals, images.image_sizes, None)
         return self.transform.postprocess(detections, images.image_sizes, original_sizes)
 
+    # ---- the inference forward pass in three parts, for engine.evaluate's pipelined loop -------------------------------------------
+    # launch_trunk: transform + trunk graph replay (no synchronisation); launch_heads: proposals to the host (one small copy: call it
+    # when the trunk has finished and it costs nothing), RoI heads, detections padded to detections_per_img rows, rescaled to the
+    # original image and copied to pinned host memory -- all queued, nothing waited for; finish: slices the pinned rows once the
+    # stream has drained.  Same tensors through the same kernels as `forward`; `None` from launch_trunk / launch_heads means
+    # "not on this path" (training, CPU, internal warping, no graph inference, shapes the detection kernels do not take).
+    def launch_trunk(self, images, killWarp=False, newMeans=None, newSTDs=None):
+        if not (self.graph_inference and not self.training and not torch.is_grad_enabled()) or (self.warp_internally and not killWarp):
+            return None
+        if not all(isinstance(i, torch.Tensor) and i.is_cuda for i in images):
+            return None
+        from ..graphs import GraphCache
+        original_sizes = [(int(img.shape[-2]), int(img.shape[-1])) for img in images]
+        batch, _ = self.transform(images, None, newMeans, newSTDs)
+        x = batch.tensors
+        n = x.shape[0]
+        sizes = self.__dict__.setdefault("_sizes", {})
+        if n not in sizes:
+            sizes[n] = torch.zeros((n, 2), dtype=x.dtype, device=x.device)
+        host = torch.tensor([[float(s[1]), float(s[0])] for s in batch.image_sizes], dtype=x.dtype).pin_memory()
+        sizes[n].copy_(host, non_blocking=True)
+        cache = self.__dict__.get("_trunk_graphs")
+        if cache is None:
+            cache = self.__dict__["_trunk_graphs"] = GraphCache(self._trunk)
+        self._sync_graphs_with_weights(cache)
+        outs = cache(x)
+        return {"images": batch, "original_sizes": original_sizes, "outs": outs, "feat_names": list(self._feat_names)}
+
+    def launch_heads(self, handle):
+        from .net_transforms import resize_boxes
+        outs, batch = handle["outs"], handle["images"]
+        features = OrderedDict(zip(handle["feat_names"], outs[:-4]))
+        proposals, _ = self.rpn.unpad(*outs[-4:-1])
+        padded = self.roi_heads.padded_detections(features, proposals, batch.image_sizes)
+        if padded is None:
+            return None
+        ring = self.__dict__.setdefault("_pinned_ring", {"slot": 0, "bufs": {}})
+        pins = []
+        for (boxes, scores, labels, count), size, original in zip(padded, batch.image_sizes, handle["original_sizes"]):
+            k = boxes.shape[0]
+            boxes = resize_boxes(boxes, size, original)                          # transform.postprocess, on the padded rows
+            slot = ring["slot"] = (ring["slot"] + 1) % 8                         # pinned rows are reused 8 images later: far beyond the pipeline's depth
+            buf = ring["bufs"].get((slot, k))
+            if buf is None:
+                buf = ring["bufs"][(slot, k)] = (torch.empty((k, 5), dtype=torch.float32).pin_memory(),
+                                                 torch.empty((k + 1,), dtype=torch.int64).pin_memory())
+            f32, i64 = buf
+            f32[:, :4].copy_(boxes, non_blocking=True)
+            f32[:, 4].copy_(scores, non_blocking=True)
+            i64[:k].copy_(labels, non_blocking=True)
+            i64[k:].copy_(count.reshape(1), non_blocking=True)
+            pins.append((f32, i64, k))
+        handle["pinned"] = pins
+        return handle
+
+    @staticmethod
+    def finish(handle):
+        """The detections of `launch_heads` as CPU tensors (the stream that ran it must have drained: engine.evaluate's next wait)."""
+        out = []
+        for f32, i64, k in handle["pinned"]:
+            n = int(i64[k])
+            out.append({"boxes": f32[:n, :4].clone(), "labels": i64[:n].clone(), "scores": f32[:n, 4].clone()})
+        return out
+
     def forward(self, images, targets=None, thetas=None, lambda1s=None, lambda2s=None, killWarp=False, newMeans=None,
                 newSTDs=None):
         if self.training and targets is None:

@@ -202,7 +202,7 @@ class RoIHeads(nn.Module):
 
     _class_ids = {}
 
-    def _detections_hip(self, class_logits, box_regression, rois, shape):
+    def _detections_hip(self, class_logits, box_regression, rois, shape, defer=False):
         """postprocess_detections of one image in ~20 launches and one host synchronisation (the final count): candidates
         class-major from one kernel, every class's candidates sorted by one top-k launch, ONE batched NMS over the classes as
         independent sets -- on boxes moved apart by class * (largest coordinate + 1), the arithmetic of torchvision's batched_nms, so
@@ -228,8 +228,27 @@ class RoIHeads(nn.Module):
         fb = b.gather(1, keep[..., None].expand(-1, -1, 4))
         k = min(D, (C - 1) * d)
         top_s, top_i, top_b, _ = ops.topk_levels_hip(fs.reshape(1, -1), [(C - 1) * d], [k], k, fb.reshape(1, -1, 4), want_index=True)
+        if defer:          # padded to k rows, the number that count on the device: the caller synchronises when it suits it
+            return top_b[0, 0], top_s[0, 0], top_i[0, 0] // d + 1, count.sum().clamp(max=D)
         n = int(count.sum().clamp(max=D))                                                                  # the one synchronisation
         return {"boxes": top_b[0, 0, :n], "labels": top_i[0, 0, :n] // d + 1, "scores": top_s[0, 0, :n]}
+
+    def padded_detections(self, features, proposals, image_shapes):
+        """Inference without any host synchronisation (engine.evaluate's pipelined loop): per image (boxes [k, 4], scores [k],
+        labels [k], number of real rows as a 0-d device tensor), or None where the kernels of `_detections_hip` do not apply."""
+        box_features = self.box_head(self.box_roi_pool(features, proposals, image_shapes))
+        class_logits, box_regression = self.box_predictor(box_features)
+        C = class_logits.shape[-1]
+        counts = [p.shape[0] for p in proposals]
+        if not (ops.hip_boxes_ok(class_logits, box_regression, *proposals) and C <= 128 and 0 < min(counts + [1]) and max(counts + [0]) <= 2048
+                and self.detections_per_img <= 2048 and (C - 1) * self.detections_per_img <= ops.TOPK_SPLIT):
+            return None
+        out, start = [], 0
+        for p, shape in zip(proposals, image_shapes):
+            R = p.shape[0]
+            out.append(self._detections_hip(class_logits[start:start + R], box_regression[start:start + R], p, shape, defer=True))
+            start += R
+        return out
 
     def forward(self, features, proposals, image_shapes, targets=None):
         if self.training:

@@ -132,3 +132,50 @@ def test_two_runs_of_evaluate_main_print_identical_coco_stats(tmp_path):
         assert a["cells"][cell] == b["cells"][cell], cell
         assert a["cells"][cell]["images"] == 4
     assert sum(c["boxes"] for c in a["cells"].values()) > 0
+
+
+def test_pipelined_evaluation_equals_the_plain_loop(monkeypatch):
+    """engine.evaluate on the GPU runs three images at once (heads of image i - 1, trunk of image i, blur / estimator of image
+    i + 1 queued before anything is waited for; detections read from pinned memory an iteration later).  Same routes, same
+    detections bit for bit, same COCO statistics as the plain one-image-at-a-time loop (DIB_NO_PIPELINE=1) -- ensemble + estimator at
+    800 x 1333, expanded boxes, 7 images (odd: the pipeline's tail), and once more with early_stop."""
+    import contextlib
+    import io
+    from torch import nn
+    from detectinblur_amd import engine, utils
+    from detectinblur_amd.coco_utils import SyntheticCocoDetection
+    from detectinblur_amd.models.blur_estimator import resnet18
+    from detectinblur_amd.models.faster_rcnn import fasterrcnn_resnet50_fpn
+    from detectinblur_amd.train import get_transform
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1337)
+    ens = [fasterrcnn_resnet50_fpn(num_classes=91, pretrained=False, pretrained_backbone=False).to(dev).eval() for _ in range(2)]
+    est = resnet18(); est.fc = nn.Linear(512, 4); est = est.to(dev).eval()
+    with contextlib.redirect_stdout(io.StringIO()):
+        tf = get_transform(False, blur=True, blur_type=0.001, blur_ratio=1, blur_exposure=0.5)
+    ds = SyntheticCocoDetection(num_images=7, size=(800, 1333), transforms=tf)
+
+    class L(list):
+        dataset = ds
+
+    batches = L(utils.collate_fn([ds[i]]) for i in range(7))
+    kw = dict(blurring_images=True, gpu_blur=True, expand_target_boxes=True, use_ensemble=True, ensemble_models=ens + ens, blur_estimator=est, LEHE=True)
+    out = {}
+    for stop in (None, 3):
+        for plain in ("", "1"):
+            if plain:
+                monkeypatch.setenv("DIB_NO_PIPELINE", "1")
+            else:
+                monkeypatch.delenv("DIB_NO_PIPELINE", raising=False)
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = engine.evaluate(None, batches, dev, early_stop=stop, **kw)
+            out[(stop, plain)] = r
+        a, b = out[(stop, "")], out[(stop, "1")]
+        assert a.routes == b.routes and len(a.routes) == (7 if stop is None else stop + 1)
+        assert list(a.detections) == list(b.detections) and len(a.detections) == len(a.routes)
+        for k in a.detections:
+            for f in ("boxes", "scores", "labels"):
+                assert a.detections[k][f].device.type == "cpu" and torch.equal(a.detections[k][f], b.detections[k][f]), (k, f)
+            assert torch.equal(a.targets[k], b.targets[k])
+        assert np.array_equal(np.asarray(a.coco_stats), np.asarray(b.coco_stats))
+        assert sum(v["scores"].numel() for v in a.detections.values()) > 50
