@@ -11,6 +11,10 @@ __version__ = "0.1.0"
 
 import os as _os
 
+# (r4) Next to the find-db sits the user PERF-db (`*.udb.txt`) of a tuning run (`scratch/tune_miopen_train.sh`:
+# MIOPEN_FIND_ENFORCE=SEARCH over the train step's convolutions, 7 minutes on one MI355X): the tile configuration of MIOpen's tunable
+# solvers per shape, measured instead of taken from their heuristics -- train step 100.0 -> 94.3 ms on the same box
+# (`scratch/t_miopen_ab.sh`).  It travels in the same private copy.
 # MIOpen picks each convolution's kernel by timing every applicable solver the first time it sees a
 # shape (~90 s for this detector at b=8 x 800x1344 on a fresh machine) and remembers the result in a
 # "user find-db".  `miopen_db/` ships that database for every shape the bench, the drivers (800 x 1333 and

@@ -77,7 +77,8 @@ def test_every_process_gets_a_private_copy_of_the_shipped_miopen_find_db():
     code = "import os, detectinblur_amd; p = os.environ.get('MIOPEN_USER_DB_PATH'); print(p); print(sorted(os.listdir(p)) if p and os.path.isdir(p) else None)"
     shipped = os.path.join(ROOT, "detectinblur_amd", "miopen_db")
     files = sorted(f for f in os.listdir(shipped) if os.path.isfile(os.path.join(shipped, f)))
-    assert files and all(f.endswith(".ufdb.txt") for f in files)
+    assert files and all(f.endswith(".ufdb.txt") or f.endswith(".udb.txt") for f in files)       # find-db (+ the tuned perf-db)
+    assert any(f.endswith(".ufdb.txt") for f in files)
 
     def run(extra):
         env = {k: v for k, v in os.environ.items() if k not in ("MIOPEN_USER_DB_PATH", "DIB_MIOPEN_DB_INPLACE", "DIB_NO_MIOPEN_DB")}
@@ -93,7 +94,7 @@ def test_every_process_gets_a_private_copy_of_the_shipped_miopen_find_db():
     assert run({"MIOPEN_USER_DB_PATH": "/tmp"})[0] == "/tmp"
     assert run({"DIB_MIOPEN_DB_INPLACE": "1"})[0] == shipped
     assert run({"DIB_NO_MIOPEN_DB": "1"})[0] == "None"
-    lines = sum(1 for _ in open(os.path.join(shipped, files[0])))
+    lines = sum(1 for _ in open(os.path.join(shipped, [f for f in files if f.endswith(".ufdb.txt")][0])))
     assert lines >= 500       # the bench's, the drivers' and the tests' shapes (scratch/fill_miopen_db.sh), not only the b = 8 training ones
 
 
