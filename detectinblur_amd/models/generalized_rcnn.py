@@ -113,9 +113,13 @@ class GeneralizedRCNN(nn.Module):
         outs, batch = handle["outs"], handle["images"]
         features = OrderedDict(zip(handle["feat_names"], outs[:-4]))
         proposals, _ = self.rpn.unpad(*outs[-4:-1])
-        padded = self.roi_heads.padded_detections(features, proposals, batch.image_sizes)
+        padded, head_outputs = self.roi_heads.padded_detections(features, proposals, batch.image_sizes)
         if padded is None:
-            return None
+            # shapes the detection kernels do not take: finish this image the plain way (with its synchronisations) right here
+            detections = self.roi_heads.postprocess_detections(head_outputs[0], head_outputs[1], proposals, batch.image_sizes)
+            detections = self.transform.postprocess(detections, batch.image_sizes, handle["original_sizes"])
+            handle["done"] = [{k: v.to("cpu") for k, v in d.items()} for d in detections]
+            return handle
         ring = self.__dict__.setdefault("_pinned_ring", {"slot": 0, "bufs": {}})
         pins = []
         for (boxes, scores, labels, count), size, original in zip(padded, batch.image_sizes, handle["original_sizes"]):
@@ -138,6 +142,8 @@ class GeneralizedRCNN(nn.Module):
     @staticmethod
     def finish(handle):
         """The detections of `launch_heads` as CPU tensors (the stream that ran it must have drained: engine.evaluate's next wait)."""
+        if "done" in handle:
+            return handle["done"]
         out = []
         for f32, i64, k in handle["pinned"]:
             n = int(i64[k])

@@ -235,20 +235,25 @@ class RoIHeads(nn.Module):
 
     def padded_detections(self, features, proposals, image_shapes):
         """Inference without any host synchronisation (engine.evaluate's pipelined loop): per image (boxes [k, 4], scores [k],
-        labels [k], number of real rows as a 0-d device tensor), or None where the kernels of `_detections_hip` do not apply."""
+        labels [k], number of real rows as a 0-d device tensor) and None -- or (None, (class_logits, box_regression)) where the
+        kernels of `_detections_hip` do not apply and the caller has to finish through `postprocess_detections`."""
         box_features = self.box_head(self.box_roi_pool(features, proposals, image_shapes))
         class_logits, box_regression = self.box_predictor(box_features)
         C = class_logits.shape[-1]
         counts = [p.shape[0] for p in proposals]
-        if not (ops.hip_boxes_ok(class_logits, box_regression, *proposals) and C <= 128 and 0 < min(counts + [1]) and max(counts + [0]) <= 2048
+        if not (ops.hip_boxes_ok(class_logits, box_regression, *proposals) and C <= 128 and max(counts + [0]) <= 2048
                 and self.detections_per_img <= 2048 and (C - 1) * self.detections_per_img <= ops.TOPK_SPLIT):
-            return None
+            return None, (class_logits, box_regression)
         out, start = [], 0
         for p, shape in zip(proposals, image_shapes):
             R = p.shape[0]
+            if R == 0:                                                   # an image without a single proposal: one padding row, none real
+                out.append((class_logits.new_zeros((1, 4)), class_logits.new_zeros((1,)), torch.zeros((1,), dtype=torch.int64, device=p.device),
+                            torch.zeros((), dtype=torch.int64, device=p.device)))
+                continue
             out.append(self._detections_hip(class_logits[start:start + R], box_regression[start:start + R], p, shape, defer=True))
             start += R
-        return out
+        return out, None
 
     def forward(self, features, proposals, image_shapes, targets=None):
         if self.training:

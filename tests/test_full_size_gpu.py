@@ -179,3 +179,42 @@ def test_pipelined_evaluation_equals_the_plain_loop(monkeypatch):
             assert torch.equal(a.targets[k], b.targets[k])
         assert np.array_equal(np.asarray(a.coco_stats), np.asarray(b.coco_stats))
         assert sum(v["scores"].numel() for v in a.detections.values()) > 50
+
+
+def test_split_forward_pass_equals_forward_and_survives_odd_cases(monkeypatch):
+    """GeneralizedRCNN.launch_trunk / launch_heads / finish (what the pipelined evaluation calls) against `forward` on the same
+    image; then with the detection kernels switched off (the heads finish through the tensor path) and with an image whose RPN
+    keeps no proposal at all (one padding row, no detection)."""
+    from detectinblur_amd.models import detector_ops as ops
+    from detectinblur_amd.models.faster_rcnn import fasterrcnn_resnet50_fpn
+    torch.manual_seed(0)
+    m = fasterrcnn_resnet50_fpn(num_classes=91, pretrained=False, pretrained_backbone=False).cuda().eval()
+    m.graph_inference = True
+    img = torch.rand(3, 800, 1088, device="cuda")
+    means, stds = np.tile([0.485, 0.456, 0.406], (1, 1)), np.tile([0.229, 0.224, 0.225], (1, 1))
+
+    def split():
+        h = m.launch_trunk([img], killWarp=True, newMeans=means, newSTDs=stds)
+        torch.cuda.synchronize()
+        assert m.launch_heads(h) is h
+        torch.cuda.synchronize()
+        return m.finish(h)[0]
+
+    with torch.no_grad():
+        for _ in range(2):
+            want = m([img], killWarp=True, newMeans=means, newSTDs=stds)[0]      # second sighting: the trunk graph is captured
+        got = split()
+        for k in ("boxes", "scores", "labels"):
+            assert got[k].device.type == "cpu" and torch.equal(got[k], want[k].cpu()), k
+        assert got["scores"].numel() > 10
+        monkeypatch.setattr(ops, "HIP_BOXES", False)
+        plain = split()
+        monkeypatch.setattr(ops, "HIP_BOXES", True)
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(plain[k], got[k]), k
+        # no proposal survives: the RPN's minimum size above every box
+        monkeypatch.setattr(m.rpn, "min_size", 1e9)
+        m.__dict__.pop("_trunk_graphs")                          # the captured trunk has the old value in its kernel arguments
+        empty = split()
+        assert empty["boxes"].shape == (0, 4) and empty["scores"].numel() == 0 and empty["labels"].dtype == torch.int64
+    assert m.launch_trunk([img.cpu()], killWarp=True) is None and m.train().launch_trunk([img], killWarp=True) is None
