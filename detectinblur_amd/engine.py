@@ -499,6 +499,7 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                 # synchronisation into evaluator updates while the GPU works.  Same tensors through the same kernels as the
                 # plain loop below (tests/test_full_size_gpu.py compares the two).
                 ready, in_flight = in_flight, []
+                gt_host = [utils.convert_to_xywh(t["boxes"]).cpu() for t in targets_GPU]      # before anything is queued: no wait
                 if trunk_running is not None:
                     if trunk_running[0].launch_heads(trunk_running[1]) is None:
                         raise RuntimeError("evaluate: the detector left the pipelined path between its trunk and its heads")
@@ -506,7 +507,7 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                     trunk_running = None
                 handle = core.launch_trunk(images_GPU, killWarp=not blurring_images, newMeans=norm_means, newSTDs=norm_stds)
                 if handle is not None:
-                    trunk_running = (core, handle, ids, [utils.convert_to_xywh(t["boxes"]).cpu() for t in targets_GPU], model_time)
+                    trunk_running = (core, handle, ids, gt_host, model_time)
                     ahead.advance(more=more)
                     for entry in ready:
                         finalize(entry)
