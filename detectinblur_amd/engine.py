@@ -457,6 +457,22 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                      and not any(getattr(getattr(m, "module", m), "warp_internally", False) and blurring_images
                                  for m in (ensemble_models if use_ensemble else [model])))
         trunk_running, in_flight = None, []
+
+        def flush():
+            """empties the pipeline, in image order: heads of the image whose trunk is running, then everything on its way"""
+            nonlocal trunk_running, in_flight
+            if trunk_running is not None:
+                torch.cuda.synchronize()
+                if trunk_running[0].launch_heads(trunk_running[1]) is None:
+                    raise RuntimeError("evaluate: the detector left the pipelined path between its trunk and its heads")
+                in_flight.append(trunk_running)
+                trunk_running = None
+            if in_flight:
+                torch.cuda.synchronize()
+                for entry in in_flight:
+                    finalize(entry)
+                in_flight = []
+
         ahead = _StagedAhead(metric_logger.log_every(data_loader, 100, "Test:"), device, blurring_images, gpu_blur or expand_target_boxes,
                              prepare, may_prepare=not (add_noise or add_block or add_jpeg_artifact))
         for _, (images_GPU, targets_GPU, blur_dicts, thetas, l1, l2, est) in ahead:
@@ -491,7 +507,9 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
             core = getattr(model, "module", model)
             ids = [int(t["image_id"]) if "image_id" in t else count for t in targets_GPU]
             handle = None
-            if pipelined and hasattr(core, "launch_trunk"):
+            if not (pipelined and hasattr(core, "launch_trunk")):
+                flush()                                                      # a detector without the split forward pass: images stay in order
+            else:
                 # Pipelined (GPU, graph inference): the queue is empty here (the synchronisation above).  Queue, in this order and
                 # without waiting for any of it: the RoI heads + detections of the PREVIOUS image (its trunk has finished: reading
                 # its proposal counts costs nothing) with their copy to pinned memory, this image's trunk, the next image's blur /
@@ -512,10 +530,8 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
                     for entry in ready:
                         finalize(entry)
                 else:                                                        # this detector does not take the path: drain, then as below
-                    for entry in ready + in_flight:
-                        torch.cuda.synchronize()
-                        finalize(entry)
-                    in_flight = []
+                    in_flight = ready + in_flight
+                    flush()
             if handle is None:
                 # the look-ahead step runs right after the detector's trunk has been launched (models/generalized_rcnn.py calls
                 # the hook between the graph replay and its first wait); a model without that hook gets it before the call
@@ -535,18 +551,7 @@ def evaluate(model, data_loader, device, distributed_mode=False, early_stop=None
             count += 1
             if early_stop is not None and count > early_stop:
                 break
-        # the pipeline's tail: heads of the last image, then everything that is still on its way
-        if trunk_running is not None:
-            torch.cuda.synchronize()
-            if trunk_running[0].launch_heads(trunk_running[1]) is None:
-                raise RuntimeError("evaluate: the detector left the pipelined path between its trunk and its heads")
-            in_flight.append(trunk_running)
-            trunk_running = None
-        if in_flight:
-            torch.cuda.synchronize()
-            for entry in in_flight:
-                finalize(entry)
-            in_flight = []
+        flush()                                                              # the pipeline's tail
     finally:                                                             # also on an error in the loop: no stray thread, thread count restored
         if scorer is not None:
             scorer.shutdown(wait=True)
