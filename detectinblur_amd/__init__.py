@@ -49,8 +49,9 @@ if not _os.environ.get("DIB_NO_MIOPEN_DB") and "MIOPEN_USER_DB_PATH" not in _os.
 # GEMMs (the 1x1 convolutions that run as GEMMs, the box head, the RPN predictor): PyTorch's TunableOp picks, per GEMM shape, the
 # fastest of hipBLASLt's and rocBLAS's solutions instead of the libraries' heuristic default -- at batch 1 the trunk's small GEMMs
 # (M = 1,050 .. 67,200 rows) run 1.3-2x faster that way (trunk replay 6.36 -> 5.71 ms, scratch/t_tunable.sh).  `tunableop/` ships the
-# recorded choices for the shapes of the bench, the drivers at 800 x 1333 / 800 x 1088 and the train step at b = 8
-# (scratch/fill_tunableop.sh regenerates it); like the find-db above the process reads a PRIVATE COPY, with tuning off: a shape
+# recorded choices for the shapes of the bench, the train step at b = 8 and batch-1 inference at every input size a COCO image reaches
+# after the detector's transform (min side 800, max side 1333, padded to 32: a grid of 53 sizes) (scratch/fill_tunableop.sh and
+# scratch/fill_dbs_grid.sh regenerate it; the find-db above covers the same grid); like the find-db above the process reads a PRIVATE COPY, with tuning off: a shape
 # that is not in the file runs on the default solution, nothing is measured at run time, every process makes the same choice.
 # The file's validator lines (PyTorch / ROCm / hipBLASLt / rocBLAS versions, gfx950) make PyTorch ignore it on any other stack.
 # An explicit PYTORCH_TUNABLEOP_ENABLED (either value) is respected; DIB_NO_TUNABLEOP=1 opts out.  Must run before the first GEMM.
