@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
+# DIB_HIP_LIB: another build of the same library (diagnostic builds of scratch/: stamps, timelines); never set in production
+LIB_PATH = os.environ.get("DIB_HIP_LIB") or os.path.join(_HERE, "libdib_hip.so")
 
 DIB_F16, DIB_F32 = 0, 1
 DIB_ACC_BITEXACT, DIB_ACC_FP32, DIB_ACC_FMA16 = 0, 1, 2

@@ -27,8 +27,7 @@
 // batch = 30.8 us of pure vector-ALU time on 1024 SIMDs, above its 13 us of HBM time.  Everything else -- window fills,
 // stores, launch ramp, drain -- has to hide behind that arithmetic, i.e. behind the other workgroups of the CU: hence
 // eight of them per CU, and hence the instruction diet of everything outside the tap loop.
-#include "dib_common.h"
-#include <hip/hip_fp16.h>
+#include "dib_compact_dev.h"
 #include <mutex>
 #include <stdlib.h>
 
@@ -577,13 +576,17 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
 }
 
-template <int ACC, bool L = false>
+// STEP (the blur step's single launch, blur_step_f16_kernel): with `early` set the segment count and the first segment come
+// from the caller (the compaction's early record: the table itself must not be touched yet) and `wait_tables()` is called
+// once, between the first window's barrier and the first tap loop -- the first reader of the table's offsets.
+struct NoWait { __device__ void operator()() const {} };
+template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait>
 __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
-                                                   unsigned *lds) {
+                                                   unsigned *lds, const int wave, const int early = 0, const int nsegs0 = 0,
+                                                   const uint4 seg0 = uint4{0, 0, 0, 0}, const Wait wait_tables = Wait()) {
 #pragma clang fp contract(off)
   constexpr int GQ = QGeom<L>::GQ;            // LDS rows a wave fills (11; large window: 15)
   constexpr int QPITCH = QGeom<L>::PITCH, QUAD_PITCH = QGeom<L>::PITCH_EL, LROWS = QGeom<L>::ROWS;   // shadow the standard geometry's constants
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int H = d.H, W = d.W, w2 = W * 2;
   const int mode = pad_mode_for(K, H, W);
   const int pb = K / 2 - 1, pa = K / 2;
@@ -592,7 +595,10 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
   int nsegs;
   uint4 seg;
-  {
+  if (STEP && early) {
+    nsegs = nsegs0 | 1 << 30;       // bit 30: "wait for the tables in front of the first tap loop" (no register of its own)
+    seg = seg0;
+  } else {
     unsigned __int128 r;
     asm volatile("s_load_dword %0, %2, 0x1c\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(nsegs), "=&s"(r) : "s"((unsigned long long)tab), "s"((unsigned long long)segs));
@@ -602,7 +608,11 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   const unsigned long long la = (unsigned long long)(tab + table_ltaps_q_off(K));
   const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
                                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
-  const int x0 = tx * QTILE_W, y0 = ty * TH;
+  // STEP: the tile's origin lives in ONE scalar register (ty << 16 | tx; tiles per channel < 2^16, dib_sparse_blur checks) and is
+  // unpacked where it is needed -- not kept as x0 and y0 across the window fill, where the step kernel has no register left.
+  const int x0c = tx * QTILE_W, y0c = ty * TH, pxy = ty << 16 | tx;
+  auto x0f = [&]() -> int { if constexpr (STEP) { int p = pxy; asm volatile("" : "+s"(p)); return (p & 0xffff) * QTILE_W; } else return x0c; };
+  auto y0f = [&]() -> int { if constexpr (STEP) { int p = pxy; asm volatile("" : "+s"(p)); return (int)((unsigned)p >> 16) * TH; } else return y0c; };
   const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(d.in, ch, H, W);
   h2 acc[8];
 #pragma unroll
@@ -616,10 +626,11 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   typedef unsigned lds_u2v __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) lds_u2v lds_u2;
 
-  for (int sg = 0; sg < nsegs; ++sg) {
+  for (int sg = 0; sg < (STEP ? (nsegs & 0xffffff) : nsegs); ++sg) {
     if (sg > 0) seg = segs[sg];
     const Window w = window_of(seg);
     const int lane = fresh_lane();
+    const int x0 = x0f(), y0 = y0f();
     // ---- fill: per LDS row the four values P[lane + 32 m] of element `lane` (large window: six values -- element 64 + lane,
     // owned by lanes 0-31, is {P[lane + 64], P[lane + 96], P[lane + 128], P[lane + 160]}, the first two shared with element lane)
     constexpr int NK = L ? 6 : 4;
@@ -711,15 +722,21 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       }
     }
     __syncthreads();
+    if constexpr (STEP) { if (sg == 0 && (nsegs >> 30)) wait_tables(); }
     const int tl = fresh_lane();
     const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
-    if (W - x0 <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true, L>(acc, ltaps, w.t0, w.n, lane_addr);
+    if (W - x0f() <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true, L>(acc, ltaps, w.t0, w.n, lane_addr);
     else tap_loop_quad<ACC == DIB_ACC_FMA16, false, L>(acc, ltaps, w.t0, w.n, lane_addr);
   }
   // ---- store: a store instruction writes 32 columns of row y (lanes 0-31) and of row y + 4 (lanes 32-63); lanes
   // outside the image get an out-of-range buffer offset and are dropped by the range check ----------------------------
   {
-    const __amdgpu_buffer_rsrc_t out_rsrc = plane_rsrc(d.out, ch, H, W);
+    // STEP: the plane offset ch * H * W * 2 is formed again here (from an opaque copy of ch) instead of staying alive from the
+    // input descriptor's across the segment loop: two scalar registers the step kernel does not have (it spilled them).
+    int chs = ch;
+    if constexpr (STEP) asm volatile("" : "+s"(chs));
+    const __amdgpu_buffer_rsrc_t out_rsrc = plane_rsrc(d.out, chs, H, W);
+    const int x0 = x0f(), y0 = y0f();
     const int sl = fresh_lane();
     const int yl = y0 + wave * 8 + (sl >> 5) * 4, xl = x0 + (sl & 31);
     const unsigned base = (unsigned)(yl * w2 + xl * 2), oob = 0x7ffffff0u;
@@ -728,7 +745,7 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       // block in the immediate offset, the high halves stored straight from the registers -- no vector instruction at all
       // (the general form below costs ~45 per wave).  Written out: there is no builtin for the d16_hi stores.
       typedef int i4v __attribute__((ext_vector_type(4)));
-      const unsigned long long pa2 = (unsigned long long)d.out + (unsigned long long)ch * H * W * 2ull;   // as plane_rsrc
+      const unsigned long long pa2 = (unsigned long long)d.out + (unsigned long long)chs * H * W * 2ull;   // as plane_rsrc
       const i4v rs = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa2), __builtin_amdgcn_readfirstlane((int)(unsigned)(pa2 >> 32)) & 0xffff,
                       H * W * 2, 0x00020000};
       int so = 0;
@@ -790,7 +807,7 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch) 
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
   const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds);
+  blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
 #ifdef DIB_TIMELINE
   if (threadIdx.x == 0) {
     unsigned long long *tl = DIB_TL_SLOT;
@@ -803,6 +820,179 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch) 
     }
   }
 #endif
+}
+
+// =============================================================================================
+// The blur STEP as ONE launch (dib_blur_step: tap compaction + blur; reference models/blur_functions.py:92-100).
+// As two launches the step pays the compaction twice over: its own ~5.5 us (8 workgroups, a latency chain) and a dependent
+// kernel boundary in front of the blur (BENCH_r04: 47.2 us per step around a 38.9 us blur).  Here the grid's first columns
+// compact (one 256-thread workgroup per PSF, tables written through to memory with sc1 stores), every blur workgroup behind
+// them waits until a counter says all tables of THIS launch are done, and the compaction runs under the launch's own ramp.
+//   Grid: x = ncx + (the blur's x), y = image; of the ncx leading columns only row 0's first n_psf blocks work, the others
+//   exit at once (ncx is a multiple of 8, so `x & 7` still names the XCD list of a blur block).
+//   Hand-off (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"), in two stages.
+//   (1) As soon as a PSF's segments are final its FIRST segment goes out as two 8-byte {data, tag} words (sc1 stores, 32 copies):
+//   a blur workgroup of that PSF's image polls one copy with sc1 loads and fills its first window from it -- the launch's first
+//   fill (every resident workgroup's window at once) then runs while the compaction still makes the per-tap offsets.
+//   (2) Everything else: payload stored sc1 -> every storing wave's s_waitcnt vmcnt(0) -> workgroup barrier -> agent-scope add
+//   to EVERY replica of the counter (one wave instruction, 32 lanes, 32 lines); the blur workgroup looks at the counter in
+//   front of its first tap loop and touches the tables -- scalar loads through the scalar cache -- only afterwards.  No acquire is needed for those: the scalar cache and this XCD's L2 are
+//   invalidated at the kernel's start and nobody reads a table line before the counter says so (ONE counter for all tables:
+//   neighbouring tables share cache lines), so neither can hold a stale copy.  Workgroups dispatched after the first rounds
+//   (linear index >= STEP_EARLY) first look at replica `x & 7` through the scalar cache: a stale value can only read low (the
+//   counter is monotonic) and falls back to the sc1 poll; early ones must not do that (they would leave the stale line in the
+//   scalar cache for the rest of the launch).
+//   Forward progress: the compacting workgroups have the grid's lowest indices and are dispatched first (observed dispatch
+//   order, relied on by every decoupled look-back scan); a poll that does not succeed within ~1 s traps instead of hanging.
+// =============================================================================================
+constexpr unsigned STEP_EARLY = 4096;
+constexpr int STEP_LDS_EXTRA = 16;      // {sync pointer, target} for StepWait, behind the window (19,728 B: still eight workgroups per CU)
+#ifdef DIB_STEP_STAMPS
+// Diagnostic build only (scratch/t_step_stamps.py): 100 MHz wall-clock stamps of the compacting workgroups (8 words each) and of
+// the blur workgroups of grid row 0 (4 words each, behind them).
+__device__ unsigned long long *g_step_stamps;
+#endif
+// The counter once more, in front of the first tap loop of a blur workgroup that started on the early record (by then it has
+// nearly always been reached, so a fresh value lands in the scalar cache; a stale one only costs the sc1 polls behind it).
+// The counter's copy is chosen by the XCD the workgroup runs on (a hardware register).
+struct StepWait {
+  unsigned lds_words;     // LDS byte address of {sync lo, sync hi, target}, written by the kernel in front of the tile function
+  // ONE asm statement on the registers the tap loops clobber anyway (s[36:41], v[45:48]: free between two of them); the three
+  // words it needs wait in 16 bytes of LDS behind the window, not in scalar registers: the kernel runs at 78 of the 80 that
+  // eight waves per SIMD allow, and three more live across the window fill spilled.
+  //   s[36:37] = sync + 128 * XCD, s38 = target; ready when (int)(counter - target) >= 0: first through the scalar cache,
+  //   then (rare) sc1 vector polls of the same copy, ~2^21 of them before the trap.
+  __device__ __forceinline__ void operator()() const {
+    static_assert(STEP_REPLICA_WORDS * 4 == 128, "the shift below");
+    asm volatile(
+        "v_mov_b32 v48, %0\n\t"
+        "ds_read_b64 v[46:47], v48\n\t"
+        "ds_read_b32 v45, v48 offset:8\n\t"
+        "s_getreg_b32 s39, hwreg(20, 0, 3)\n\t"              /* HW_REG_XCC_ID[2:0] */
+        "s_lshl_b32 s39, s39, 7\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 s36, v46\n\t"
+        "v_readfirstlane_b32 s37, v47\n\t"
+        "v_readfirstlane_b32 s38, v45\n\t"
+        "s_add_u32 s36, s36, s39\n\t"
+        "s_addc_u32 s37, s37, 0\n\t"
+        "s_load_dword s40, s[36:37], 0x0\n\t"
+        "s_mov_b32 s41, 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_sub_u32 s40, s40, s38\n\t"
+        "s_cmp_lt_i32 s40, 0\n\t"
+        "s_cbranch_scc0 Ldibw_done%=\n\t"
+        "v_mov_b32 v48, 0\n\t"
+        "Ldibw_poll%=:\n\t"
+        "global_load_dword v48, v48, s[36:37] sc1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_readfirstlane_b32 s40, v48\n\t"
+        "v_mov_b32 v48, 0\n\t"
+        "s_sub_u32 s40, s40, s38\n\t"
+        "s_cmp_lt_i32 s40, 0\n\t"
+        "s_cbranch_scc0 Ldibw_done%=\n\t"
+        "s_sleep 2\n\t"
+        "s_add_u32 s41, s41, 1\n\t"
+        "s_cmp_lt_u32 s41, 0x200000\n\t"
+        "s_cbranch_scc1 Ldibw_poll%=\n\t"
+        "s_trap 2\n\t"
+        "Ldibw_done%=:"
+        :: "s"(lds_words)
+        : "s36", "s37", "s38", "s39", "s40", "s41", "v45", "v46", "v47", "v48", "scc", "memory");
+  }
+};
+
+template <int ACC>
+__global__ __launch_bounds__(256, 8) void blur_step_f16_kernel(BlurBatch batch, StepSync sy, PsfPtrs psfs) {
+  constexpr int K = 128;
+  extern __shared__ unsigned nlds[];
+  // First scalar round trip: the launch's hand-off words and the image descriptor, requested together (a compacting
+  // workgroup fetches a descriptor it does not need rather than every blur workgroup waiting twice).
+  const ImageDesc d = batch.img[blockIdx.y];
+  asm volatile("" ::"s"(d.in), "s"(d.out), "s"(d.C), "s"(d.H), "s"(d.W), "s"(d.table), "s"(d.tiles_x), "s"(d.tiles_y),
+               "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab), "s"(sy.sync), "s"(sy.target), "s"(sy.ncx), "s"(sy.row), "s"(sy.rec));
+  // the ONE consumer of the thread-index register in this kernel (dib_compact_dev.h: compact_psf_f16_wg256)
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (blockIdx.x < (unsigned)sy.ncx) {
+    if (blockIdx.y == 0 && blockIdx.x < (unsigned)sy.n_psf) {
+      unsigned *rec = sy.rec + (size_t)blockIdx.x * (STEP_REPLICAS * STEP_REC_WORDS);
+#ifdef DIB_STEP_STAMPS
+      unsigned long long *dbg = *(unsigned long long *volatile *)&g_step_stamps;
+      if (dbg) dbg += 8 * blockIdx.x;
+      compact_psf_f16_wg256<true, true>(psfs.p[blockIdx.x], sy.flags, sy.tables + (size_t)blockIdx.x * table_words(K), nlds, wave, rec, sy.target, dbg);
+#else
+      compact_psf_f16_wg256<true, true>(psfs.p[blockIdx.x], sy.flags, sy.tables + (size_t)blockIdx.x * table_words(K), nlds, wave, rec, sy.target);
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its sc1 stores have left
+      __syncthreads();
+      const int t = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#ifdef DIB_STEP_STAMPS
+      if (dbg && t == 0) dbg[6] = __builtin_amdgcn_s_memrealtime();
+#endif
+      if (t < STEP_REPLICAS)
+        __hip_atomic_fetch_add(sy.sync + t * STEP_REPLICA_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef DIB_STEP_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (dbg && t == 0) dbg[7] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+    return;
+  }
+  const unsigned bx = blockIdx.x - (unsigned)sy.ncx;
+  const int per_ch = d.tiles_x * d.tiles_y;
+  int local;
+  if (!band_entry(d.C * per_ch, bx & 7, bx >> 3, local)) __builtin_amdgcn_endpgm();
+#ifdef DIB_STEP_STAMPS
+  unsigned long long *bdbg = *(unsigned long long *volatile *)&g_step_stamps;
+  if (bdbg && blockIdx.y == 0 && wave == 0) { bdbg += 8 * MAX_BATCH + 4 * bx; bdbg[0] = __builtin_amdgcn_s_memrealtime(); } else bdbg = nullptr;
+#endif
+  // ---- are the tables of this launch complete?  (the counter, through the scalar cache: late workgroups only) ----
+  int early = 1;      // an integer in ONE scalar register (as a bool hipcc keeps it as a 64-bit lane mask and spills that)
+  if (blockIdx.y * (unsigned)sy.row + blockIdx.x >= STEP_EARLY) {
+    unsigned c;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "s"(sy.sync + (blockIdx.x & 7) * STEP_REPLICA_WORDS) : "memory");
+    early = (int)((c - sy.target) >> 31);
+  }
+  asm volatile("" : "+s"(early));
+  // the counter once more, in front of the first tap loop of a workgroup that started early: StepWait below
+  int nsegs0 = 0;
+  uint4 seg0 = make_uint4(0, 0, 0, 0);
+  if (early) {   // ---- the first segment of this image's PSF, from the compaction's early record (sc1 polls of one copy) ----
+    const unsigned long long *pr = reinterpret_cast<const unsigned long long *>(sy.rec + ((size_t)d.table * STEP_REPLICAS + (blockIdx.x & (STEP_REPLICAS - 1))) * STEP_REC_WORDS);
+    for (unsigned spins = 0;; ++spins) {
+      const unsigned long long ra = __hip_atomic_load(pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long rb = __hip_atomic_load(pr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned ta = __builtin_amdgcn_readfirstlane((unsigned)(ra >> 32)), tb = __builtin_amdgcn_readfirstlane((unsigned)(rb >> 32));
+      if (ta == sy.target && tb == sy.target) {
+        const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)ra), b2 = __builtin_amdgcn_readfirstlane((unsigned)rb);
+        nsegs0 = (int)(a >> 16);
+        seg0 = make_uint4(0u, a & 0xffffu, b2 >> 16, b2 & 0xffffu);
+        break;
+      }
+      if (spins > (1u << 21)) __builtin_trap();
+      __builtin_amdgcn_s_sleep(2);
+    }
+    // what StepWait needs, into the 16 bytes of LDS behind the window (every wave's lane 0 writes the same three words)
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+      nlds[QLDS_BYTES / 4] = (unsigned)(unsigned long long)sy.sync;
+      nlds[QLDS_BYTES / 4 + 1] = (unsigned)((unsigned long long)sy.sync >> 32);
+      nlds[QLDS_BYTES / 4 + 2] = sy.target;
+    }
+    asm volatile("" ::: "memory");
+  }
+#ifdef DIB_STEP_STAMPS
+  if (bdbg) bdbg[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int ch = magic_div(local, d.inv_per_ch);
+  local -= ch * per_ch;
+  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
+  blur_quad_tile_f16<ACC, false, true>(d, d.tab, K, ch, tx, ty, nlds, wave, early, nsegs0, seg0, StepWait{(unsigned)(size_t)(__attribute__((address_space(3))) char *)nlds + QLDS_BYTES});
+#ifdef DIB_STEP_STAMPS
+  if (bdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bdbg[2] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+  // A hard end: hipcc otherwise funnels every exit through one block placed behind the compaction code and keeps values of
+  // this path alive for it across the tile function, whose window fill has no register to spare (a spill to scratch memory).
+  __builtin_amdgcn_endpgm();
 }
 
 // The same tile function on the LARGE window (39.9 KB of LDS: 4 workgroups per CU, so up to 128 registers per lane cost
@@ -818,7 +1008,7 @@ __global__ __launch_bounds__(256, 4) void blur_quad_large_f16_kernel(BlurBatch b
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
   const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  blur_quad_tile_f16<ACC, true>(d, d.tab, K, ch, tx, ty, nlds);
+  blur_quad_tile_f16<ACC, true>(d, d.tab, K, ch, tx, ty, nlds, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
 }
 
 template <int ACC>
@@ -900,6 +1090,9 @@ using namespace dib;
 static unsigned long long *g_stamp_buffer = nullptr;
 extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) {
   g_stamp_buffer = (unsigned long long *)dev_ptr;
+#ifdef DIB_STEP_STAMPS
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(dib::g_step_stamps), &g_stamp_buffer, sizeof(g_stamp_buffer));
+#endif
 #ifdef DIB_TIMELINE
   (void)hipMemcpyToSymbol(HIP_SYMBOL(dib::g_timeline), &g_stamp_buffer, sizeof(g_stamp_buffer));
 #endif
@@ -947,6 +1140,8 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 256>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_step_f16_kernel<DIB_ACC_BITEXACT>), QLDS_BYTES + STEP_LDS_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_step_f16_kernel<DIB_ACC_FMA16>), QLDS_BYTES + STEP_LDS_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_large_f16_kernel<DIB_ACC_BITEXACT, 128>), QGeom<true>::BYTES));
     DIB_HIP_CHECK(opt_in((blur_quad_large_f16_kernel<DIB_ACC_FMA16, 128>), QGeom<true>::BYTES));
     DIB_HIP_CHECK(opt_in((blur_quad_large_f16_kernel<DIB_ACC_BITEXACT, 256>), QGeom<true>::BYTES));
@@ -957,23 +1152,10 @@ int prepare_device() {
 }
 }  // namespace
 
-extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, const int *C, const int *H,
-                               const int *W, const int *table_index, int B, int dtype, void *tables_dev,
-                               int num_tables, int K, int acc_mode, void *stream) {
-  if (B < 0 || (B > 0 && (!in_dev || !out_dev || !C || !H || !W || !table_index || !tables_dev))) {
-    set_error("dib_sparse_blur: null pointer or negative batch");
-    return DIB_EINVAL;
-  }
-  if (K != 128 && K != 256) { set_error("dib_sparse_blur: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
-  if (dtype != DIB_F16 && dtype != DIB_F32) { set_error("dib_sparse_blur: unknown dtype %d", dtype); return DIB_EINVAL; }
-  const bool large = (acc_mode & DIB_WINDOW_LARGE) != 0;      // the tables were compacted with DIB_COMPACT_LARGE_WINDOW
-  acc_mode &= ~DIB_WINDOW_LARGE;
-  if (large && (dtype != DIB_F16 || acc_mode == DIB_ACC_FP32 || g_shape != 0)) {
-    set_error("dib_sparse_blur: DIB_WINDOW_LARGE serves fp16 images in DIB_ACC_BITEXACT / DIB_ACC_FMA16 on the default tile shape only");
-    return DIB_EINVAL;
-  }
-  if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FP32 && acc_mode != DIB_ACC_FMA16) { set_error("dib_sparse_blur: unknown accumulation mode %d", acc_mode); return DIB_EINVAL; }
-  if (acc_mode != DIB_ACC_BITEXACT && dtype != DIB_F16) { set_error("dib_sparse_blur: DIB_ACC_FP32 / DIB_ACC_FMA16 apply to fp16 images only (fp32 images already accumulate in fp32)"); return DIB_EINVAL; }
+namespace {
+// Per-image argument checks shared by dib_sparse_blur and the blur step's single launch.
+int check_images(const void *const *in_dev, void *const *out_dev, const int *C, const int *H, const int *W, const int *table_index, int B,
+                 int K, int num_tables) {
   for (int i = 0; i < B; ++i) {
     if (table_index[i] < 0) continue;
     if (!in_dev[i] || !out_dev[i] || C[i] <= 0 || H[i] <= 0 || W[i] <= 0) {
@@ -997,6 +1179,107 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   if (num_tables <= 0) { set_error("dib_sparse_blur: num_tables must be positive"); return DIB_EINVAL; }
   for (int i = 0; i < B; ++i)
     if (table_index[i] >= num_tables) { set_error("dib_sparse_blur: table_index[%d] = %d out of range", i, table_index[i]); return DIB_EINVAL; }
+  return DIB_OK;
+}
+
+// Descriptor of image i for the default ("quad") tiles.
+ImageDesc quad_desc(const void *in, void *out, int C, int H, int W, int table, const int *tables, int K, int tile_begin) {
+  ImageDesc d;
+  d.in = in; d.out = out; d.C = C; d.H = H; d.W = W; d.table = table;
+  d.tiles_x = (W + QTILE_W - 1) / QTILE_W;
+  d.tiles_y = (H + TH - 1) / TH;
+  d.inv_per_ch = magic_inverse((unsigned)(d.tiles_x * d.tiles_y));
+  d.inv_tiles_x = magic_inverse((unsigned)d.tiles_x);
+  d.tab = tables + (size_t)table * table_words(K);
+  d.tile_begin = tile_begin;
+  return d;
+}
+
+// x extent of the quad grid: 8 x the longest per-XCD band of the launch's images
+int quad_grid_x(const BlurBatch &b) {
+  int gx = 0;
+  for (int k = 0; k < b.n; ++k) {
+    const int T = b.img[k].C * b.img[k].tiles_x * b.img[k].tiles_y;
+    int longest = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int len = (((x + 1) * T) >> 3) - ((x * T) >> 3);
+      longest = len > longest ? len : longest;
+    }
+    gx = 8 * longest > gx ? 8 * longest : gx;
+  }
+  return gx;
+}
+}  // namespace
+
+// The step's single launch: off with DIB_STEP_FUSED=0 (A/B runs and the tests that compare the two paths).
+static int step_fused_from_env() {
+  const char *e = getenv("DIB_STEP_FUSED");
+  return !(e && e[0] == '0' && !e[1]);
+}
+static int g_step_fused = step_fused_from_env();
+extern "C" void dib_debug_set_step_fused(int on) { g_step_fused = on ? 1 : 0; }
+
+int dib::blur_step_fused_launch(const void *const *psf_ptrs, int num_psfs, int normalize, const void *const *in_dev, void *const *out_dev,
+                                const int *C, const int *H, const int *W, const int *table_index, int B, int acc_mode, int *tables,
+                                unsigned *sync, unsigned *rec, unsigned target, hipStream_t s) {
+  if (!g_step_fused || g_shape != 0 || num_psfs > MAX_BATCH || (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FMA16)) return 1;
+  if (B < 0 || (B > 0 && (!in_dev || !out_dev || !C || !H || !W || !table_index))) {
+    set_error("dib_blur_step: null pointer or negative batch");
+    return DIB_EINVAL;
+  }
+  int active = 0;
+  for (int i = 0; i < B; ++i) active += table_index[i] >= 0;
+  if (active == 0 || active > MAX_BATCH) return 1;
+  if (int rc = check_images(in_dev, out_dev, C, H, W, table_index, B, 128, num_psfs)) return rc;
+  PsfPtrs pp;
+  for (int i = 0; i < num_psfs; ++i) {
+    if (!psf_ptrs[i] || ((uintptr_t)psf_ptrs[i] & 15) != 0) { set_error("dib_psf_compact: PSF %d is null or not 16-byte aligned", i); return DIB_EINVAL; }
+    pp.p[i] = psf_ptrs[i];
+  }
+  if (int rc = prepare_device()) return rc;
+  BlurBatch tiled;
+  tiled.n = 0;
+  int tiles = 0;
+  for (int i = 0; i < B; ++i) {
+    if (table_index[i] < 0) continue;
+    const ImageDesc d = quad_desc(in_dev[i], out_dev[i], C[i], H[i], W[i], table_index[i], tables, 128, tiles);
+    tiled.tile_begin[tiled.n] = tiles;
+    tiles += d.C * d.tiles_x * d.tiles_y;
+    tiled.img[tiled.n++] = d;
+  }
+  for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
+  tiled.total_tiles = tiles;
+  tiled.xcd_bands = 1;
+  StepSync sy;
+  sy.sync = sync; sy.rec = rec; sy.target = target; sy.n_psf = num_psfs; sy.ncx = (num_psfs + 7) & ~7; sy.tables = tables;
+  sy.row = sy.ncx + quad_grid_x(tiled);
+  sy.flags = (normalize & ~DIB_COMPACT_LARGE_WINDOW) ? COMPACT_NORMALIZE : 0;
+  { static const int skip = getenv("DIB_STEP_DEBUG_SKIP") ? 1 : 0; if (skip) sy.flags |= COMPACT_DEBUG_SKIP; }   // diagnostics: the hand-off alone
+  const dim3 grid(sy.row, tiled.n);
+  if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_step_f16_kernel<DIB_ACC_FMA16>), grid, dim3(256), QLDS_BYTES + STEP_LDS_EXTRA, s, tiled, sy, pp);
+  else hipLaunchKernelGGL((blur_step_f16_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), QLDS_BYTES + STEP_LDS_EXTRA, s, tiled, sy, pp);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
+}
+
+extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, const int *C, const int *H,
+                               const int *W, const int *table_index, int B, int dtype, void *tables_dev,
+                               int num_tables, int K, int acc_mode, void *stream) {
+  if (B < 0 || (B > 0 && (!in_dev || !out_dev || !C || !H || !W || !table_index || !tables_dev))) {
+    set_error("dib_sparse_blur: null pointer or negative batch");
+    return DIB_EINVAL;
+  }
+  if (K != 128 && K != 256) { set_error("dib_sparse_blur: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
+  if (dtype != DIB_F16 && dtype != DIB_F32) { set_error("dib_sparse_blur: unknown dtype %d", dtype); return DIB_EINVAL; }
+  const bool large = (acc_mode & DIB_WINDOW_LARGE) != 0;      // the tables were compacted with DIB_COMPACT_LARGE_WINDOW
+  acc_mode &= ~DIB_WINDOW_LARGE;
+  if (large && (dtype != DIB_F16 || acc_mode == DIB_ACC_FP32 || g_shape != 0)) {
+    set_error("dib_sparse_blur: DIB_WINDOW_LARGE serves fp16 images in DIB_ACC_BITEXACT / DIB_ACC_FMA16 on the default tile shape only");
+    return DIB_EINVAL;
+  }
+  if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FP32 && acc_mode != DIB_ACC_FMA16) { set_error("dib_sparse_blur: unknown accumulation mode %d", acc_mode); return DIB_EINVAL; }
+  if (acc_mode != DIB_ACC_BITEXACT && dtype != DIB_F16) { set_error("dib_sparse_blur: DIB_ACC_FP32 / DIB_ACC_FMA16 apply to fp16 images only (fp32 images already accumulate in fp32)"); return DIB_EINVAL; }
+  if (int rc = check_images(in_dev, out_dev, C, H, W, table_index, B, K, num_tables)) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = prepare_device()) return rc;
   int i = 0;

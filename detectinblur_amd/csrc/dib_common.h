@@ -33,7 +33,7 @@ static_assert(WIN_PITCH >= 64 + SEG_COLS, "window row too short for a segment");
 // is told which by its caller.
 constexpr int SEG_ROWS_L = 20, SEG_COLS_L = 63, QUAD_PITCH_L = 32 + SEG_COLS_L + 1;   // 96 elements per LDS row
 static_assert(QUAD_PITCH_L == 96, "the large window's fill writes elements lane and 64 + lane");
-constexpr int COMPACT_NORMALIZE = 1, COMPACT_NO_SEGMENTS = 4, COMPACT_LARGE_WINDOW = 8;   // flag bits of the compaction kernel
+constexpr int COMPACT_NORMALIZE = 1, COMPACT_NO_SEGMENTS = 4, COMPACT_LARGE_WINDOW = 8, COMPACT_DEBUG_SKIP = 0x100;   // flag bits of the compaction kernel
 
 __host__ __device__ inline int table_rowptr_off() { return HDR_WORDS; }
 __host__ __device__ inline int table_taps_off(int K) { return (HDR_WORDS + K + 1 + 3) & ~3; }
@@ -69,6 +69,11 @@ __device__ inline int map_coord(int s, int n, int pa, int pb, int mode, bool &ze
 void set_error(const char *fmt, ...);
 // dib_compact.hip: the launch behind dib_psf_compact_list; any_order = hipExtAnyOrderLaunch (see dib_step.hip)
 int compact_launch(const void *const *ptrs, int dtype, int B, int K, int normalize, int *tables, hipStream_t s, bool any_order);
+// dib_blur.hip: compaction + blur as ONE launch (fp16 PSFs and images, K = 128, default tiles, at most MAX_BATCH of each).
+// Returns 1 when the arguments are outside what that launch serves (nothing launched: the caller takes the two-launch path).
+int blur_step_fused_launch(const void *const *psf_ptrs, int num_psfs, int normalize, const void *const *in_dev, void *const *out_dev,
+                           const int *C, const int *H, const int *W, const int *table_index, int B, int acc_mode, int *tables,
+                           unsigned *sync, unsigned *rec, unsigned target, hipStream_t s);
 
 #define DIB_HIP_CHECK(expr)                                                          \
   do {                                                                               \
@@ -100,6 +105,30 @@ struct ImageDesc {
 // n / d for n * d < 2^32, inv = floor(2^32 / d) + 1 (exact: the error term n * (inv * d - 2^32) / (d * 2^32) stays below 1 / d)
 __host__ __device__ inline unsigned magic_inverse(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / d) + 1u; }
 __device__ __forceinline__ int magic_div(int n, unsigned inv) { return inv ? (int)__umulhi((unsigned)n, inv) : n; }
+
+// PSF pointers travel by value in the kernel-argument buffer: a batch whose PSFs live in separate
+// tensors (the reference's `psfs_GPU` list, engine.py:84) needs no torch.stack copy.
+struct PsfPtrs { const void *p[MAX_BATCH]; };
+
+// The blur step's single launch (dib_blur.hip: blur_step_f16_kernel; dib_step.hip owns the buffers).  `sync`: STEP_REPLICAS
+// copies of one monotonic counter, each on a 128-byte line of its own; every compacting workgroup adds 1 to every copy once its
+// table is written through to memory, a blur workgroup reads the tables once its copy has reached `target` (the value the
+// counter has when all of THIS launch's n_psf tables are done; compared as a signed difference, so it may wrap).
+constexpr int STEP_REPLICAS = 32, STEP_REPLICA_WORDS = 32, STEP_REC_WORDS = 32;
+struct StepSync {
+  unsigned *sync;     // STEP_REPLICAS x STEP_REPLICA_WORDS words
+  unsigned target;
+  int n_psf;          // PSFs (= compacting workgroups) of this launch
+  int ncx;            // grid columns in front of the blur's: n_psf rounded up to a multiple of 8
+  int flags;          // the compaction's flag word (COMPACT_NORMALIZE | ...)
+  int row;            // grid x extent (= ncx + the blur's columns): a block's linear index is y * row + x
+  int *tables;        // n_psf tables, table_words(K) apart
+  // First-segment records: per PSF STEP_REPLICAS copies, each on a 128-byte line of its own, of two 8-byte words {data, tag}:
+  // {end of the first segment | segments << 16, tag}, {(r_first << 8 | r_last) << 16 | cmin << 8 | cmax, tag}; tag = `target`.
+  // Written (sc1) as soon as the PSF's segments are final, long before its offsets are: a blur workgroup that finds both tags
+  // fills its first window from these words and looks at the counter only in front of its first tap loop.
+  unsigned *rec;      // MAX_BATCH x STEP_REPLICAS x STEP_REC_WORDS words
+};
 
 struct BlurBatch {
   ImageDesc img[MAX_BATCH];

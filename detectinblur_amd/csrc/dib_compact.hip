@@ -11,135 +11,14 @@
 // division is an IEEE fp32 divide rounded to fp16, which equals a correctly rounded fp16 divide
 // (24 >= 2*11+2).  Order of the output taps = row-major, the order of torch.nonzero: every thread
 // owns K*K/1024 CONSECUTIVE elements, so thread order is element order.
-#include "dib_common.h"
+#include "dib_compact_dev.h"
 #include <hip/hip_ext.h>
-#include <hip/hip_fp16.h>
 #include <vector>
 
 namespace dib {
 
-__device__ inline long long half_bits_to_fixed(unsigned short h) {
-  // value * 2^24 as an exact integer (inf/nan map to a huge sentinel that poisons the sum)
-  int sign = h >> 15, e = (h >> 10) & 31, m = h & 1023;
-  long long v;
-  if (e == 0) v = m;                       // subnormal: m * 2^-24
-  else if (e == 31) v = (1ll << 60);       // inf / nan: out of contract
-  else v = (long long)(m | 1024) << (e - 1);
-  return sign ? -v : v;
-}
-
-__device__ inline unsigned short fixed_to_half_bits(long long total) {
-  // exact integer in units of 2^-24 -> fp16, round to nearest even
-  unsigned short sign = total < 0 ? 0x8000 : 0;
-  unsigned long long m = total < 0 ? (unsigned long long)(-total) : (unsigned long long)total;
-  if (m == 0) return sign;
-  int nbits = 64 - __clzll((long long)m);
-  if (nbits <= 10) return sign | (unsigned short)m;            // subnormal, exact
-  int shift = nbits - 11;                                       // keep 11 significant bits
-  unsigned long long q = m >> shift, rem = m & ((1ull << shift) - 1);
-  if (shift > 0) {
-    unsigned long long half = 1ull << (shift - 1);
-    if (rem > half || (rem == half && (q & 1))) q++;
-  }
-  if (q == 2048) { q = 1024; shift++; }
-  int e = shift + 1;                                            // biased exponent (value = q * 2^(shift-24))
-  if (e >= 31) return sign | 0x7c00;                            // overflow -> inf
-  return sign | (unsigned short)((e << 10) | (q & 1023));
-}
-
-template <typename T> struct Elem;
-template <> struct Elem<__half> {
-  using Acc = long long;
-  static __device__ Acc lift(__half v) { return half_bits_to_fixed(__half_as_ushort(v)); }
-  static __device__ __half finish(Acc a) { return __ushort_as_half(fixed_to_half_bits(a)); }
-  static __device__ __half div(__half a, __half b) { return __float2half_rn(__half2float(a) / __half2float(b)); }
-  static __device__ bool nonzero(__half v) { return (__half_as_ushort(v) & 0x7fff) != 0; }
-  static __device__ unsigned bits(__half v) { return __half_as_ushort(v); }
-  static __device__ __half from_bits(unsigned b) { return __ushort_as_half((unsigned short)b); }
-};
-template <> struct Elem<float> {
-  // fp32 PSFs (manual_blur with fp32 operands): torch's fp32 sum order is implementation
-  // defined; this path accumulates in fp64 in a fixed order and rounds once.
-  using Acc = double;
-  static __device__ Acc lift(float v) { return (double)v; }
-  static __device__ float finish(Acc a) { return (float)a; }
-  static __device__ float div(float a, float b) { return a / b; }
-  static __device__ bool nonzero(float v) { return v != 0.0f; }
-  static __device__ unsigned bits(float v) { return __float_as_uint(v); }
-  static __device__ float from_bits(unsigned b) { return __uint_as_float(b); }
-};
-
-template <typename A> __device__ inline A wave_sum(A v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-// ---- wave64 reductions / scan on the DPP path -------------------------------------------------------
-// __shfl_* compile to ds_bpermute_b32: ~100 cycles of latency each, and a 6-step reduction is a chain
-// of them (x2 for 64-bit values).  Row-level DPP moves run at VALU rate; the four row results are
-// collected with v_readlane.  dpp0: lanes without a source read 0; dppk: they keep `keep`.
-template <int CTRL> __device__ inline int dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-template <int CTRL> __device__ inline int dppk(int v, int keep) { return __builtin_amdgcn_update_dpp(keep, v, CTRL, 0xf, 0xf, false); }
-constexpr int QUAD_SWAP1 = 0xB1, QUAD_SWAP2 = 0x4E, ROW_SHR1 = 0x111, ROW_SHR2 = 0x112, ROW_SHR4 = 0x114, ROW_SHR8 = 0x118;
-
-__device__ inline int wave_sum_i32(int x) {   // wave-uniform result
-  x += dpp0<QUAD_SWAP1>(x); x += dpp0<QUAD_SWAP2>(x);   // every lane: its quad's sum
-  x += dpp0<ROW_SHR4>(x); x += dpp0<ROW_SHR8>(x);       // lanes 12..15 of a row: the row's sum
-  return __builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31) + __builtin_amdgcn_readlane(x, 47) +
-         __builtin_amdgcn_readlane(x, 63);
-}
-__device__ inline int wave_min_i32(int x) {
-  x = min(x, dppk<QUAD_SWAP1>(x, x)); x = min(x, dppk<QUAD_SWAP2>(x, x));
-  x = min(x, dppk<ROW_SHR4>(x, x)); x = min(x, dppk<ROW_SHR8>(x, x));
-  return min(min(__builtin_amdgcn_readlane(x, 15), __builtin_amdgcn_readlane(x, 31)),
-             min(__builtin_amdgcn_readlane(x, 47), __builtin_amdgcn_readlane(x, 63)));
-}
-__device__ inline int wave_max_i32(int x) {
-  x = max(x, dppk<QUAD_SWAP1>(x, x)); x = max(x, dppk<QUAD_SWAP2>(x, x));
-  x = max(x, dppk<ROW_SHR4>(x, x)); x = max(x, dppk<ROW_SHR8>(x, x));
-  return max(max(__builtin_amdgcn_readlane(x, 15), __builtin_amdgcn_readlane(x, 31)),
-             max(__builtin_amdgcn_readlane(x, 47), __builtin_amdgcn_readlane(x, 63)));
-}
-__device__ inline int wave_scan_incl_i32(int x, int lane) {   // inclusive prefix sum over the 64 lanes
-  x += dpp0<ROW_SHR1>(x); x += dpp0<ROW_SHR2>(x); x += dpp0<ROW_SHR4>(x); x += dpp0<ROW_SHR8>(x);
-  const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
-  const int row = lane >> 4;
-  return x + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
-}
-__device__ inline int wave_scan_min_i32(int x, int lane) {   // inclusive prefix minimum (identity: INT_MAX)
-  constexpr int ID = 0x7fffffff;
-  x = min(x, dppk<ROW_SHR1>(x, ID)); x = min(x, dppk<ROW_SHR2>(x, ID)); x = min(x, dppk<ROW_SHR4>(x, ID)); x = min(x, dppk<ROW_SHR8>(x, ID));
-  const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
-  const int row = lane >> 4;
-  return min(x, min(row > 0 ? r0 : ID, min(row > 1 ? r1 : ID, row > 2 ? r2 : ID)));
-}
-__device__ inline int wave_scan_max_i32(int x, int lane) {   // inclusive prefix maximum (identity: INT_MIN)
-  constexpr int ID = (int)0x80000000;
-  x = max(x, dppk<ROW_SHR1>(x, ID)); x = max(x, dppk<ROW_SHR2>(x, ID)); x = max(x, dppk<ROW_SHR4>(x, ID)); x = max(x, dppk<ROW_SHR8>(x, ID));
-  const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
-  const int row = lane >> 4;
-  return max(x, max(row > 0 ? r0 : ID, max(row > 1 ? r1 : ID, row > 2 ? r2 : ID)));
-}
-// exact 64-bit sum as three limbs (21 + 21 + 22 bits): every limb's 64-lane sum fits 32 bits, and the
-// recombination is arithmetic mod 2^64, so negative (two's complement) inputs come out right
-__device__ inline long long wave_sum(long long v) {
-  const unsigned long long u = (unsigned long long)v;
-  const unsigned long long s0 = (unsigned)wave_sum_i32((int)(u & 0x1fffffu));
-  const unsigned long long s1 = (unsigned)wave_sum_i32((int)((u >> 21) & 0x1fffffu));
-  const unsigned long long s2 = (unsigned)wave_sum_i32((int)(u >> 42));
-  return (long long)(s0 + (s1 << 21) + (s2 << 42));
-}
-
-// sum over the wave, same value in every lane
-__device__ inline long long wave_total(long long v) { return wave_sum(v); }                 // limb path: already uniform
-__device__ inline double wave_total(double v) { return __shfl(wave_sum(v), 0, 64); }         // shuffle path: lane 0 holds it
-
 constexpr int CT = 1024;          // threads per PSF
 constexpr int STAGE_TAPS = 4096;  // (row<<8|col) of the first taps are staged in LDS for the segmenter
-
-// PSF pointers travel by value in the kernel-argument buffer: a batch whose PSFs live in separate
-// tensors (the reference's `psfs_GPU` list, engine.py:84) needs no torch.stack copy.
-struct PsfPtrs { const void *p[MAX_BATCH]; };
 
 template <typename T, int K>
 __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int normalize, int *__restrict__ tables) {
@@ -347,67 +226,8 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   if (wave != 0) return;
   if (normalize & COMPACT_NO_SEGMENTS) return;  // diagnostics: skip the segmentation
 
-  // ---- segmentation (wave 0): greedy runs with row span <= SEG_ROWS and column span <= SEG_COLS --------
-  uint4 *segs = reinterpret_cast<uint4 *>(tab + table_segs_off(K));
-  unsigned *ltaps = reinterpret_cast<unsigned *>(tab + table_ltaps_off(K));
-  unsigned *ltaps_q = reinterpret_cast<unsigned *>(tab + table_ltaps_q_off(K));
-  // segment limits and the quad window's row pitch of the geometry this table is compacted for (dib_common.h)
-  const bool large = (normalize & COMPACT_LARGE_WINDOW) != 0;
-  const int seg_rows = large ? SEG_ROWS_L : SEG_ROWS, seg_cols = large ? SEG_COLS_L : SEG_COLS, qpitch = large ? QUAD_PITCH_L : QUAD_PITCH;
-  // per-tap LDS offsets of a closed segment [s0, s1) with last row rl and last column cmx
-  auto emit_ltaps = [&](int s0, int s1, int rl, int cmx) {
-    for (int j = s0 + lane; j < s1; j += 64) {
-      unsigned rcj, wj;
-      if (j < STAGE_TAPS) { rcj = s_rc[j]; wj = s_wb[j] & 0xffffu; }
-      else { const uint2 tp = taps[j]; rcj = tp.x & 0xffffu; wj = tp.y & 0xffffu; }
-      const int rj = rcj >> 8, cj = rcj & 255;
-      ltaps[j] = (unsigned)(((rl - rj) * WIN_PITCH + (cmx - cj)) * 8) | (wj << 16);
-      ltaps_q[j] = (unsigned)(((rl - rj) * qpitch + (cmx - cj)) * 8) | (wj << 16);
-    }
-  };
-  int nseg = 0, seg_start = 0, seg_r0 = 0, seg_rlast = 0, car_cmin = 1 << 20, car_cmax = -1;
-  for (int base = 0; base < ntaps; base += 64) {
-    const int i = base + lane;
-    const bool valid = i < ntaps;
-    unsigned rc = 0;
-    if (valid) rc = (i < STAGE_TAPS) ? s_rc[i] : (taps[i].x & 0xffffu);
-    const int r = rc >> 8, c = rc & 255;
-    if (base == 0) seg_r0 = __builtin_amdgcn_readlane(r, 0);
-    int lo = 0;
-    while (true) {
-      // inclusive prefix min / max of c over lanes [lo, lane], joined with the open segment's carry
-      int pm = wave_scan_min_i32((valid && lane >= lo) ? c : (1 << 20), lane);
-      int px = wave_scan_max_i32((valid && lane >= lo) ? c : -1, lane);
-      pm = min(pm, car_cmin); px = max(px, car_cmax);
-      const bool bad = valid && lane >= lo && ((r - seg_r0 > seg_rows) || (px - pm > seg_cols));
-      const unsigned long long fail = __ballot(bad);
-      const unsigned long long vmask = __ballot(valid);
-      const int last_valid = 63 - __clzll((long long)vmask);  // vmask != 0 inside the loop
-      if (fail == 0) {
-        car_cmin = __builtin_amdgcn_readlane(pm, last_valid); car_cmax = __builtin_amdgcn_readlane(px, last_valid);
-        seg_rlast = __builtin_amdgcn_readlane(r, last_valid);
-        break;
-      }
-      const int f = __ffsll((long long)fail) - 1;  // tap base+f opens a new segment
-      int cmn = car_cmin, cmx = car_cmax, rl = seg_rlast;
-      if (f > lo) { cmn = __builtin_amdgcn_readlane(pm, f - 1); cmx = __builtin_amdgcn_readlane(px, f - 1); rl = __builtin_amdgcn_readlane(r, f - 1); }
-      if (lane == 0) segs[nseg] = make_uint4(seg_start, base + f, (seg_r0 << 8) | rl, (cmn << 8) | cmx);
-      emit_ltaps(seg_start, base + f, rl, cmx);
-      ++nseg;
-      seg_start = base + f;
-      seg_r0 = __builtin_amdgcn_readlane(r, f);
-      seg_rlast = seg_r0;
-      car_cmin = 1 << 20; car_cmax = -1;
-      lo = f;
-    }
-  }
-  if (ntaps > 0) {
-    if (lane == 0) segs[nseg] = make_uint4(seg_start, ntaps, (seg_r0 << 8) | seg_rlast, (car_cmin << 8) | car_cmax);
-    emit_ltaps(seg_start, ntaps, seg_rlast, car_cmax);
-    ++nseg;
-  }
-  if (lane < 8) ltaps[ntaps + lane] = ltaps_q[ntaps + lane] = 0;  // the blur's scalar prefetch runs up to two taps past the end
-  if (lane == 0) tab[HDR_NSEGS] = nseg;
+  // ---- segmentation (wave 0): dib_compact_dev.h ----
+  segment_taps<false, STAGE_TAPS>(tab, K, normalize, ntaps, s_rc, s_wb, lane);
 }
 
 }  // namespace dib
@@ -472,4 +292,23 @@ extern "C" int dib_psf_compact_list(const void *const *psf_ptrs, int dtype, int 
   int rc = check_compact_args(psf_ptrs, tables_dev, dtype, B, K);
   if (rc != DIB_OK || B == 0) return rc;
   return launch_compact(psf_ptrs, dtype, B, K, normalize, (int *)tables_dev, (hipStream_t)stream);
+}
+
+// Test hook (not part of the drop-in boundary): the 256-thread compaction of the blur step's single launch
+// (dib_compact_dev.h: compact_psf_f16_wg256, write-through stores) on its own, into caller tables, so that the parity tests
+// can compare its tables with the stand-alone kernel's word by word.  fp16 PSFs, K = 128, B <= 32.
+namespace dib {
+__global__ __launch_bounds__(256, 8) void psf_compact_wg256_kernel(PsfPtrs ptrs, int flags, int *__restrict__ tables) {
+  extern __shared__ unsigned pool[];
+  compact_psf_f16_wg256<true>(ptrs.p[blockIdx.x], flags, tables + (size_t)blockIdx.x * table_words(128), pool, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
+}
+}  // namespace dib
+extern "C" int dib_debug_compact_wg256(const void *const *psf_ptrs, int B, int normalize, void *tables_dev, void *stream) {
+  if (!psf_ptrs || !tables_dev || B < 1 || B > dib::MAX_BATCH) { dib::set_error("dib_debug_compact_wg256: bad arguments"); return DIB_EINVAL; }
+  dib::PsfPtrs pp;
+  for (int i = 0; i < B; ++i) pp.p[i] = psf_ptrs[i];
+  const int flags = ((normalize & ~DIB_COMPACT_LARGE_WINDOW) ? dib::COMPACT_NORMALIZE : 0) | ((normalize & DIB_COMPACT_LARGE_WINDOW) ? dib::COMPACT_LARGE_WINDOW : 0);
+  hipLaunchKernelGGL(dib::psf_compact_wg256_kernel, dim3(B), dim3(256), 19712, (hipStream_t)stream, pp, flags, (int *)tables_dev);
+  DIB_HIP_CHECK(hipGetLastError());
+  return DIB_OK;
 }

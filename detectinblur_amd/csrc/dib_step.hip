@@ -26,8 +26,12 @@ using namespace dib;
 namespace {
 struct Slot {
   int *buf = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0;        // of the tables; behind them (256-byte aligned) sit the single launch's counter replicas
+  unsigned *sync = nullptr;
+  unsigned target = 0;     // value the counter replicas reach when the slot's last single launch has compacted all its PSFs
 };
+constexpr size_t COUNTER_BYTES = (size_t)STEP_REPLICAS * STEP_REPLICA_WORDS * sizeof(unsigned);
+constexpr size_t SYNC_BYTES = COUNTER_BYTES + (size_t)MAX_BATCH * STEP_REPLICAS * STEP_REC_WORDS * sizeof(unsigned);   // + the first-segment records
 
 struct StepState {
   Slot slot[2];
@@ -78,8 +82,21 @@ extern "C" int dib_blur_step(const void *const *psf_ptrs, int psf_dtype, int num
       DIB_HIP_CHECK(hipFree(sl.buf));
       sl.buf = nullptr; sl.bytes = 0;
     }
-    DIB_HIP_CHECK(hipMalloc((void **)&sl.buf, need));
+    const size_t tab_bytes = (need + 255) & ~(size_t)255;
+    DIB_HIP_CHECK(hipMalloc((void **)&sl.buf, tab_bytes + SYNC_BYTES));
     sl.bytes = need;
+    sl.sync = (unsigned *)((char *)sl.buf + tab_bytes);
+    sl.target = 0;
+    DIB_HIP_CHECK(hipMemsetAsync(sl.sync, 0, SYNC_BYTES, s));      // stream-ordered in front of the first launch that counts
+  }
+  // One launch for the whole step where the shapes allow it (dib_blur.hip: blur_step_f16_kernel); else compaction + blur.
+  if (K == 128 && psf_dtype == DIB_F16 && dtype == DIB_F16 && !(flags & DIB_STEP_LARGE_WINDOW)) {
+    const int rc = blur_step_fused_launch(psf_ptrs, num_psfs, normalize, in_dev, out_dev, C, H, W, table_index, B, acc_mode, sl.buf, sl.sync,
+                                          (unsigned *)((char *)sl.sync + COUNTER_BYTES), sl.target + (unsigned)num_psfs, s);
+    if (rc <= 0) {
+      if (rc == DIB_OK) { sl.target += (unsigned)num_psfs; ++st.next; }
+      return rc;
+    }
   }
   if (int rc = compact_launch(psf_ptrs, psf_dtype, num_psfs, K, normalize, sl.buf, s, (flags & DIB_STEP_PSFS_COMPLETE) != 0)) return rc;
   ++st.next;   // from here on the buffer counts as in use by this step, whatever the blur returns
