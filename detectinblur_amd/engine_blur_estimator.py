@@ -4,10 +4,11 @@ engine_blur_estimator.py:82-130 (labels), :132-298 (train_one_epoch), :300-492 (
 The estimator is the ResNet-18 classifier that routes an image to one of the specialised detectors
 (`evaluate.py --use_ensemble`): 16 classes (sharp + 3 blur types x 5 exposures) or 4 classes with
 `LEHE_blur_seg` (low exposure of any type, or high exposure of type 1 / 2 / 3).  It trains on the same
-on-GPU motion blur as the detector, so the hot path is the same two HIP launches per batch
+on-GPU motion blur as the detector, so the hot path is the same HIP launch per batch
 (`models/blur_functions.blur_image_list`); the reference's private copy of the roll loop (:27-79) adds an
 optional bilinear resize to 800 px around the blur (`resize_images`), kept here as two stock
-`interpolate` calls around the same kernel.
+`interpolate` calls around the same kernel.  Both loops are pinned against the reference's own functions run in
+the build container (oracle/gen_detector_pins.py: `estimator`; tests/test_blur_estimator.py).
 """
 import math
 import sys
@@ -58,8 +59,12 @@ def accuracy(output, target, topk=(1,)):
 # ---- blur with the optional 800-px round trip ----------------------------------------------------------
 
 def blur_image_list(images_GPU, blur_dicts, psfs_GPU, resize_images=False):
-    """reference :69-79.  With resize_images every blurred image is brought to height 800 (aspect kept,
-    portrait images transposed first), blurred, and brought back -- bilinear both ways (:33-44, :66-72)."""
+    """reference :69-79 around its private `manual_blur` (:27-67).  With resize_images every blurred image is first brought to
+    height 800 (bilinear, aspect kept; a portrait image is transposed first and stays transposed), blurred, CROPPED to its
+    ORIGINAL height x width from the top-left corner -- the reference takes `image_height` / `image_width` before the resize and
+    crops the padded result with them (:29-30, :64) -- and that crop is interpolated to the original size (:66-72; a no-op
+    resample unless the crop ran into the resized image's edge).  Pinned by tests/golden/detector_pins.json
+    (`estimator/*/blur_resize_quant`): the blur is the same HIP launch, on the resized image."""
     if not resize_images:
         return blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU)
     shapes, work = {}, list(images_GPU)
@@ -77,9 +82,8 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, resize_images=False):
         work[i] = F.interpolate(x, size=(800, new_w), mode="bilinear").squeeze(0)
     blur_functions.blur_image_list(work, blur_dicts, psfs_GPU)
     for i, (h, w) in shapes.items():
-        # the reference interpolates the blurred (still transposed, for portrait images) tensor straight to
-        # (image_height, image_width) without transposing back (:66-72); reproduced as is
-        images_GPU[i] = F.interpolate(work[i].unsqueeze(0), size=(h, w), mode="bilinear").squeeze(0).squeeze()
+        crop = work[i][..., :h, :w]                     # `output[:, :, 63:63 + image_height, 63:63 + image_width]` of the padded result
+        images_GPU[i] = F.interpolate(crop.unsqueeze(0), size=(h, w), mode="bilinear").squeeze()
     return None
 
 
@@ -116,7 +120,9 @@ def _stage(images_CPU, blur_dicts, device, with_psfs):
 
 
 def _targets(blur_dicts, device, LEHE_blur_seg):
-    t = torch.zeros(len(blur_dicts), dtype=torch.long)
+    # the reference starts from a uniformly random label vector (drawn on the host from torch's default generator, :228-236,
+    # :404-414) and overwrites every entry; the draw is kept so that a seeded run consumes the generator as the reference does
+    t = torch.zeros(len(blur_dicts), requires_grad=False).uniform_(0, 3 if LEHE_blur_seg else 15).long()
     t = (get_target_from_blur_dict_LEHE if LEHE_blur_seg else get_target_from_blur_dict)(blur_dicts, t)
     return t.to(device)
 
@@ -127,6 +133,8 @@ def train_one_epoch(model, optimizer, criterion, data_loader, device, print_freq
                     writer=None, gpu_blur=False, LEHE_blur_seg=False, resize_images=False, quantize_image=False,
                     crop_images=False, add_noise=False, noise_level=0.001, add_block=False, add_jpeg_artifact=False,
                     early_stop=None, blur_train=False):
+    """reference :132-298, argument for argument.  Pinned against the reference's own function on a toy classifier
+    (oracle/gen_detector_pins.py -> tests/test_blur_estimator.py): weights, losses, label vectors, LR trajectory, scalars."""
     jpeg = _jpeg(device) if add_jpeg_artifact else None
     batcher = GeneralizedRCNNTransform(800, 1333, IMAGE_MEAN, IMAGE_STD, crop_images=crop_images)
     model.train()
@@ -138,23 +146,34 @@ def train_one_epoch(model, optimizer, criterion, data_loader, device, print_freq
     it = 0
     for images_CPU, targets, blur_dicts in logger.log_every(data_loader, print_freq, "Epoch: [{}]".format(epoch)):
         images, psfs = _stage(images_CPU, blur_dicts, device, blur_train)
+        targets_dev = [{k: v.to(device) for k, v in t.items()} for t in targets]
         if gpu_blur and blur_train:
             blur_image_list(images, blur_dicts, psfs, resize_images)
         images = _post(images, add_noise, noise_level, add_block, quantize_image, jpeg)
-        batch = batcher([im.float() for im in images])[0].tensors
+        batch = batcher([im.float() for im in images], targets_dev)[0].tensors
         target = _targets(blur_dicts, device, LEHE_blur_seg)
-        loss = criterion(model(batch), target)
-        reduced = utils.reduce_dict({"loss": loss})["loss"]
-        value = reduced.item()
+        loss_dict = {"loss": criterion(model(batch), target)}
+        losses = sum(loss for loss in loss_dict.values())
+        loss_dict_reduced = utils.reduce_dict(loss_dict)
+        losses_reduced = sum(loss for loss in loss_dict_reduced.values())
+        value = losses_reduced.item()
+        if writer is not None and (not distributed_mode or torch.distributed.get_rank() == 0) and it % print_freq == 0:
+            step = it + epoch * len(data_loader)
+            for key, item in loss_dict_reduced.items():
+                writer.add_scalar("losses/" + key, item, step)
+            writer.add_scalar("losses/overallLoss", value, step)
+            writer.add_scalar("learningRate", optimizer.param_groups[0]["lr"], step)
         if not math.isfinite(value):
             print("Loss is {}, stopping training".format(value))
+            print(loss_dict_reduced)
             sys.exit(1)
         optimizer.zero_grad()
-        loss.backward()
+        losses.backward()
         optimizer.step()
         if lr_scheduler is not None:
             lr_scheduler.step()
-        logger.update(loss=reduced, lr=optimizer.param_groups[0]["lr"])
+        logger.update(loss=losses_reduced)
+        logger.update(lr=optimizer.param_groups[0]["lr"])
         it += 1
         if early_stop is not None and it > early_stop:
             break
@@ -165,37 +184,59 @@ def train_one_epoch(model, optimizer, criterion, data_loader, device, print_freq
 def evaluate(model, data_loader, device, distributed_mode=False, blurring_images=False, gpu_blur=False, LEHE_blur_seg=False,
              send_back_preds_targets=False, add_jpeg_artifact=False, resize_images=False, quantize_image=False,
              add_noise=False, noise_level=0.001, add_block=False, early_stop=None):
-    """Top-1 / top-2 accuracy of the estimator; returns (top1, top2[, predictions, targets])."""
+    """reference :301-492, argument for argument and return for return: `accuracies` = [top-1, top-2] in per cent over the images
+    seen, or (accuracies, targetsAll, predsAll) with `send_back_preds_targets` -- the lists hold `target[0]` and `pred[0]` of
+    every batch, as the reference's do (it evaluates with batch size 1, train_blur_estimator.py:206; with larger batches its
+    per-class summary fails on the stacked shapes, and so does this one).  Prints the reference's three summary lines."""
+    n_threads = torch.get_num_threads()
     jpeg = _jpeg(device) if add_jpeg_artifact else None
     batcher = GeneralizedRCNNTransform(800, 1333, IMAGE_MEAN, IMAGE_STD)
+    torch.set_num_threads(1)
     model.eval()
     logger = utils.MetricLogger(delimiter="  ")
-    seen, hit1, hit2, preds, tgts = 0, 0.0, 0.0, [], []
-    for n, (images_CPU, targets, blur_dicts) in enumerate(logger.log_every(data_loader, 100, "Test:")):
-        t0 = time.time()
+    count, total = 0, 0
+    correctCounts = [0, 0]
+    targetsAll, predsAll = [], []
+    topk = (1, 2)
+    for images_CPU, targets, blur_dicts in logger.log_every(data_loader, 100, "Test:"):
+        model_time = time.time()
         images, psfs = _stage(images_CPU, blur_dicts, device, blurring_images)
-        if gpu_blur and blurring_images:
+        if gpu_blur:
+            if psfs is None:      # the reference reads `psfs_GPU`, which only `blurring_images` assigns (:352-358, :361)
+                raise UnboundLocalError("local variable 'psfs_GPU' referenced before assignment")
             blur_image_list(images, blur_dicts, psfs, resize_images)
         images = _post(images, add_noise, noise_level, add_block, quantize_image, jpeg)
-        out = model(batcher([im.float() for im in images])[0].tensors)
+        outputs = model(batcher([im.float() for im in images])[0].tensors)
+        model_time = time.time() - model_time
+        evaluator_time = time.time()
         target = _targets(blur_dicts, device, LEHE_blur_seg)
-        a1, a2 = accuracy(out, target, topk=(1, 2))
-        b = target.numel()
-        seen += b
-        hit1 += float(a1) * b / 100.0
-        hit2 += float(a2) * b / 100.0
-        if send_back_preds_targets:
-            preds.append(out.argmax(1).cpu())
-            tgts.append(target.cpu())
-        logger.update(model_time=time.time() - t0)
-        if early_stop is not None and n >= early_stop:
+        total += target.size(0)
+        pred = outputs.topk(max(topk), 1, True, True)[1].t()
+        correct = pred.eq(target.view(1, -1).expand_as(pred))
+        targetsAll.append(target[0])
+        predsAll.append(pred[0])
+        for k_index, k in enumerate(topk):
+            correctCounts[k_index] += correct[:k].reshape(-1).float().sum(0, keepdim=True)
+        logger.update(model_time=model_time, evaluator_time=time.time() - evaluator_time)
+        count += 1
+        if early_stop is not None and count > early_stop:
             break
-    stats = torch.tensor([seen, hit1, hit2], dtype=torch.float64, device=device)
-    if utils.is_dist_avail_and_initialized():
-        torch.distributed.all_reduce(stats)
-    seen, hit1, hit2 = stats.tolist()
-    top1, top2 = 100.0 * hit1 / max(seen, 1), 100.0 * hit2 / max(seen, 1)
-    print("Blur estimator accuracy: top-1 {:.2f} %  top-2 {:.2f} %  ({:d} images)".format(top1, top2, int(seen)))
+    logger.synchronize_between_processes()
+    accuracies = [100 * (correctCounts[0].item() / total), 100 * (correctCounts[1].item() / total)]
+    print("Top 1 Accuracy: {0:.2f}%".format(accuracies[0]))
+    print("Top 2 Accuracy: {0:.2f}%".format(accuracies[1]))
+    mergedPreds = torch.stack(predsAll).squeeze()
+    mergedTargets = torch.stack(targetsAll).squeeze()
+    totalAcc, valid_class_count = 0, 0
+    for classInd in range(4):                       # the reference's summary looks at labels 0..3 whatever the label set (:470)
+        class_count = int((mergedTargets == classInd).sum())
+        if class_count == 0:
+            continue
+        valid_class_count += 1
+        totalAcc += int(torch.logical_and(mergedTargets == classInd, mergedPreds == mergedTargets).sum()) / class_count
+    totalAcc = totalAcc / valid_class_count
+    print("Top 1 Mean Acc: {0:.2f}%".format(totalAcc * 100))
+    torch.set_num_threads(n_threads)
     if send_back_preds_targets:
-        return top1, top2, torch.cat(preds) if preds else torch.empty(0), torch.cat(tgts) if tgts else torch.empty(0)
-    return top1, top2
+        return accuracies, targetsAll, predsAll
+    return accuracies

@@ -93,7 +93,7 @@ def main(args):
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, sampler=train_sampler, num_workers=args.workers,
                                          collate_fn=utils.collate_fn, drop_last=True, pin_memory=pin, worker_init_fn=_seed_worker,
                                          multiprocessing_context=mp_ctx)
-    loader_test = torch.utils.data.DataLoader(dataset_test, batch_size=args.batch_size, sampler=test_sampler,
+    loader_test = torch.utils.data.DataLoader(dataset_test, batch_size=1, sampler=test_sampler,      # reference train_blur_estimator.py:206
                                               num_workers=args.workers, collate_fn=utils.collate_fn, pin_memory=pin,
                                               worker_init_fn=_seed_worker, multiprocessing_context=mp_ctx)
 

@@ -11,6 +11,8 @@ Runs, in THIS container only, the reference's own files through oracle/ref_harne
                                 -> weights, losses, LR trajectory, TensorBoard scalars             (A15)
                                 `evaluate` on CPU (toy detectors / estimator, recording evaluator)
                                 -> detections handed to the evaluator, expanded ground truth, routes (A17)
+  * `engine_blur_estimator.py`  `train_one_epoch` / `evaluate` on CPU (toy classifier; 16-way and LEHE labels, blur on / off,
+                                the 800-pixel round trip, quantisation, block artefacts, crop batcher, early stop)  (f4)
 and writes tests/golden/detector_pins.json + detector_pins.npz.  Inputs come from oracle/pin_inputs.py, which the
 tests re-use; outputs are data.  Usage:  python oracle/gen_detector_pins.py
 """
@@ -167,6 +169,67 @@ def gen_eval(pins, store):
     pins["eval"] = out
 
 
+# ---- f4: the blur estimator's own loops --------------------------------------------------------------------------------
+
+def _run_est_train(est, case):
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = PI.ToyClassifier(case["classes"], 1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    model.lr_probe = opt
+    writer = PI.RecordingWriter()
+    loader = PI.est_batches(case["kind"], train=True)
+    losses = []
+    criterion = torch.nn.CrossEntropyLoss()
+
+    def crit(output, target):
+        loss = criterion(output, target)
+        losses.append({"loss": float(loss.detach()), "target": target.tolist(), "logits0": [float(v) for v in output[0].detach()]})
+        return loss
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        est.train_one_epoch(model, opt, crit, loader, torch.device("cpu"), print_freq=2, writer=writer, distributed_mode=True,
+                            **case["kw"])
+    return model, opt, writer, losses
+
+
+def gen_estimator(pins, store):
+    """The reference's engine_blur_estimator.train_one_epoch / evaluate on CPU (toy classifier, seeded batches and blur dicts):
+    weights, every loss and label vector, the LR trajectory, TensorBoard scalars; accuracies, predictions, targets and the
+    printed summary of evaluate.  Its blur is its own copy of the roll loop, with the 800-pixel round trip of `resize_images`."""
+    est = ref_harness.load_estimator_engine()
+    eng = ref_harness.load_engine()
+    out = {"train": {}, "eval": {}}
+    with _cpu_engine(eng):
+        for name, case in PI.est_train_cases().items():
+            model, opt, writer, losses = _run_est_train(est, case)
+            for k, v in model.state_dict().items():
+                store["est_train_%s_%s" % (name, k)] = v.numpy().copy()
+            out["train"][name] = {"steps": len(model.calls), "calls": model.calls, "final_lr": opt.param_groups[0]["lr"],
+                                  "losses": losses, "scalars": writer.scalars}
+    with _cpu_engine(eng, group=False):       # with a group its meters synchronise through device='cuda' (utils.py:498)
+        for name, case in PI.est_eval_cases().items():
+            torch.manual_seed(0)
+            np.random.seed(0)
+            model = PI.ToyClassifier(case["classes"], 2)
+            loader = PI.est_batches(case["kind"], train=False)
+            logits = []
+            hook = model.register_forward_hook(lambda m, i, o: logits.append([float(v) for v in o[0].detach()]))
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                ret = est.evaluate(model, loader, torch.device("cpu"), distributed_mode=True, **case["kw"])
+            hook.remove()
+            rec = {"batches": len(model.calls), "calls": model.calls, "logits": logits,
+                   "printed": [ln for ln in buf.getvalue().splitlines() if ln.startswith("Top ")]}
+            if case["kw"].get("send_back_preds_targets"):
+                acc, tg, pr = ret
+                rec.update(accuracies=[float(a) for a in acc], targets=[int(t) for t in tg], preds=[int(p) for p in pr])
+            else:
+                rec.update(accuracies=[float(a) for a in ret])
+            out["eval"][name] = rec
+    pins["estimator"] = out
+
+
 def main():
     pins, store = {}, {}
     # first: the reference's models/net_transforms.py binds `ImageList` at import time, and the estimator's crop
@@ -177,6 +240,7 @@ def main():
     gen_routers(pins)
     gen_train(pins, store)
     gen_eval(pins, store)
+    gen_estimator(pins, store)
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "detector_pins.json"), "w") as f:
         json.dump(pins, f, indent=1)
@@ -186,6 +250,8 @@ def main():
     print("router grid:", len(pins["router_oracle"]), "oracle batches,", len(pins["router_estimator"]), "estimations")
     print("train:", {k: v["steps"] for k, v in pins["train"].items()})
     print("eval:", {k: (v["routes"], v["faulty_line"]) for k, v in pins["eval"].items()})
+    print("estimator train:", {k: (v["steps"], round(v["losses"][-1]["loss"], 4)) for k, v in pins["estimator"]["train"].items()})
+    print("estimator eval:", {k: (v["batches"], v["accuracies"]) for k, v in pins["estimator"]["eval"].items()})
     print("wrote", OUT)
 
 

@@ -197,6 +197,8 @@ def blurimage_modes():
              kwargs=dict(prob=1, blur_type=2, blur_exposure=3, use_stored_psfs=True)),
         dict(name="stored_all", seed=1346, calls=4, kwargs=dict(prob=0.9, use_stored_psfs=True)),
         dict(name="stored_high", seed=1347, calls=3, kwargs=dict(prob=1, high_exposure=True, use_stored_psfs=True)),
+        # defocus: a Gaussian of random width over the PSF, then division by the maximum (reference transforms.py:338-342)
+        dict(name="dilate", seed=1348, calls=2, kwargs=dict(prob=1, low_exposure=True, dilate_psf=True)),
     ]
 
 

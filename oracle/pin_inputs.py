@@ -478,3 +478,77 @@ def build_eval_models(case, device="cpu"):
     ens = [ToyDetector(20 + k).to(device) for k in range(case["ensemble"])] or None
     est = ToyEstimator(case["estimator"], 3).to(device) if case["estimator"] else None
     return model, ens, est
+
+
+# ---- f4: the blur estimator's own loops (reference engine_blur_estimator.py:132-298, :301-492) -------------------------------
+
+class ToyClassifier(nn.Module):
+    """Stands where the ResNet-18 blur estimator stands in `engine_blur_estimator.train_one_epoch` / `evaluate`: the batched,
+    normalised, resized image in, logits out.  Every pixel (after blur, quantisation, block artefacts, normalisation, resize and
+    padding) reaches the logits through a strided convolution and a spatial mean."""
+
+    def __init__(self, n_classes, seed=0):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 6, 5, stride=4, padding=2)
+        self.fc = nn.Linear(6, n_classes)
+        _seeded(self, 3000 + seed)
+        self.calls = []            # per forward: batch shape, dtype, the LR of `lr_probe`, training flag
+        self.lr_probe = None
+
+    def forward(self, x):
+        self.calls.append({"shape": list(x.shape), "dtype": str(x.dtype), "training": self.training,
+                           "lr": None if self.lr_probe is None else self.lr_probe.param_groups[0]["lr"]})
+        return self.fc(torch.tanh(self.conv(x)).mean(dim=(2, 3)))
+
+
+def est_train_cases():
+    """name -> (loader kind, kwargs of engine_blur_estimator.train_one_epoch, classes)."""
+    c = collections.OrderedDict()
+    blur = dict(blur_train=True, gpu_blur=True)
+    c["plain16"] = dict(kind="plain", kw=dict(), classes=16)
+    c["blur16"] = dict(kind="blur", kw=dict(blur), classes=16)
+    c["blur_lehe"] = dict(kind="blur_label", kw=dict(blur, LEHE_blur_seg=True), classes=4)
+    c["blur_lehe_epoch1_crop"] = dict(kind="blur", kw=dict(blur, LEHE_blur_seg=True, epoch=1, crop_images=True), classes=4)
+    c["blur_resize_quant"] = dict(kind="blur_portrait", kw=dict(blur, resize_images=True, quantize_image=True), classes=16)
+    c["blur_block_early_stop"] = dict(kind="blur", kw=dict(blur, add_block=True, early_stop=2), classes=16)
+    c["blur_train_without_gpu_blur"] = dict(kind="blur", kw=dict(blur_train=True, gpu_blur=False), classes=16)
+    return c
+
+
+def est_eval_cases():
+    c = collections.OrderedDict()
+    blur = dict(blurring_images=True, gpu_blur=True)
+    c["plain16"] = dict(kind="plain", kw=dict(), classes=16)
+    c["blur16"] = dict(kind="blur", kw=dict(blur), classes=16)
+    c["blur_lehe_send_back"] = dict(kind="blur_label", kw=dict(blur, LEHE_blur_seg=True, send_back_preds_targets=True), classes=4)
+    c["blur_resize_quant"] = dict(kind="blur_portrait", kw=dict(blur, resize_images=True, quantize_image=True), classes=16)
+    c["blur_block_early_stop"] = dict(kind="blur", kw=dict(blur, add_block=True, early_stop=1, LEHE_blur_seg=True), classes=4)
+    return c
+
+
+def est_batches(kind, train):
+    """Training: 5 batches x 2 images; evaluation: 5 batches x 1 image (reference train_blur_estimator.py:206).  Sizes >= 65 (the
+    reflect branch); `blur_portrait` makes image 0 higher than wide (the reference's resize round trip transposes those and
+    crops with the ORIGINAL height and width, engine_blur_estimator.py:33-44, :64-72); `blur_label` gives one dict per batch an
+    explicit `blur_est_label`."""
+    rs = np.random.RandomState(9021 if train else 9022)
+    loader = ListLoader()
+    for k in range(5):
+        if kind == "blur_portrait":
+            shapes = [(3, 96 + 2 * k, 70), (3, 68, 88 + k)]
+        else:
+            shapes = [(3, 70 + 2 * k, 90), (3, 80, 75 + k)]
+        if not train:
+            shapes = shapes[k % 2:k % 2 + 1]
+        images = tuple(torch.from_numpy(rs.random_sample(s).astype(np.float32)) for s in shapes)
+        targets = tuple(_target(rs, s[1], s[2], 2 + (k + j) % 2, 10 * k + j) for j, s in enumerate(shapes))
+        if kind == "plain":
+            dicts = tuple({"blurring": False, "psf": [0], "param_index": None, "fraction_index": None} for _ in shapes)
+        else:
+            dicts = [_blur_dict(rs, (k + j) % 3, (2 * k + 3 * j) % 6, not (j == 1 and k % 2 == 1)) for j in range(len(shapes))]
+            if kind == "blur_label" and k % 2 == 0:
+                dicts[0]["blur_est_label"] = (k // 2 + 1) % 4
+            dicts = tuple(dicts)
+        loader.append((images, targets, dicts))
+    loader.dataset = object()
+    return loader

@@ -132,3 +132,15 @@ def load_engine():
         if name not in sys.modules:
             sys.modules[name] = mock.MagicMock(name=name)
     return importlib.import_module("engine")
+
+
+def load_estimator_engine():
+    """The reference's engine_blur_estimator.py (`train_one_epoch`, `evaluate`, its private `manual_blur` with the optional
+    800-pixel round trip, the label functions; row f4).  Same stubs as `load_engine`; the caller patches
+    `torch.cuda.synchronize` (engine_blur_estimator.py:257, :261, :347) to a no-op on this GPU-less container and selects the
+    `.to(device)` branches with `distributed_mode=True`."""
+    load_net_transforms()
+    for name in _EXTRA_STUBS + ["coco_eval", "coco_utils"]:
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock(name=name)
+    return importlib.import_module("engine_blur_estimator")
