@@ -576,13 +576,74 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
 }
 
+// DIB_ACC_FP32 on the quad shape: acc32 = fma(float(P), float(w), acc32) per pixel and tap, taps in the same order, ONE rounding
+// to fp16 at the store -- the product of two fp16 values is exact in fp32, so this equals the unfused form bit for bit (the
+// oracle restates it with numpy float32).  One v_fma_mix_f32 per pixel-tap (both fp16 factors converted inside the
+// instruction, the weight straight from the high half of the ltap's scalar register, the pixel from either half of the 8-byte
+// element: op_sel), i.e. HALF the vector-ALU time of the bit-exact mode's multiply + add; same window, same reads, same
+// one-tap LDS look-ahead and 6-way unrolled scalar side as tap_loop_quad.  Sixteen fp32 accumulators per lane: acc[4 i + m] =
+// row i, column j + 32 m.  Operands: %0-%15 accumulators, %16 byte offset of the next ltap pair, %17 taps left, %18 ltaps,
+// %19 lane base.
+#define DIBF_MIX(b, i, hs, W) "v_fma_mix_f32 %" #i ", " W ", v" #b ", %" #i " op_sel:[1," #hs ",0] op_sel_hi:[1,1,0]\n\t"
+#define DIBF_ROWS_X(W) DIBF_MIX(32, 0, 0, W) DIBF_MIX(32, 1, 1, W) DIBF_MIX(33, 2, 0, W) DIBF_MIX(33, 3, 1, W) DIBF_MIX(34, 4, 0, W) DIBF_MIX(34, 5, 1, W) DIBF_MIX(35, 6, 0, W) DIBF_MIX(35, 7, 1, W) \
+  DIBF_MIX(36, 8, 0, W) DIBF_MIX(36, 9, 1, W) DIBF_MIX(37, 10, 0, W) DIBF_MIX(37, 11, 1, W) DIBF_MIX(38, 12, 0, W) DIBF_MIX(38, 13, 1, W) DIBF_MIX(39, 14, 0, W) DIBF_MIX(39, 15, 1, W)
+#define DIBF_ROWS_Y(W) DIBF_MIX(40, 0, 0, W) DIBF_MIX(40, 1, 1, W) DIBF_MIX(41, 2, 0, W) DIBF_MIX(41, 3, 1, W) DIBF_MIX(42, 4, 0, W) DIBF_MIX(42, 5, 1, W) DIBF_MIX(43, 6, 0, W) DIBF_MIX(43, 7, 1, W) \
+  DIBF_MIX(44, 8, 0, W) DIBF_MIX(44, 9, 1, W) DIBF_MIX(45, 10, 0, W) DIBF_MIX(45, 11, 1, W) DIBF_MIX(46, 12, 0, W) DIBF_MIX(46, 13, 1, W) DIBF_MIX(47, 14, 0, W) DIBF_MIX(47, 15, 1, W)
+// HALF (at most 64 valid columns): the first word {P[k], P[k+32]} of every element only
+#define DIBF_ROWSH_X(W) DIBF_MIX(32, 0, 0, W) DIBF_MIX(32, 1, 1, W) DIBF_MIX(34, 4, 0, W) DIBF_MIX(34, 5, 1, W) DIBF_MIX(36, 8, 0, W) DIBF_MIX(36, 9, 1, W) DIBF_MIX(38, 12, 0, W) DIBF_MIX(38, 13, 1, W)
+#define DIBF_ROWSH_Y(W) DIBF_MIX(40, 0, 0, W) DIBF_MIX(40, 1, 1, W) DIBF_MIX(42, 4, 0, W) DIBF_MIX(42, 5, 1, W) DIBF_MIX(44, 8, 0, W) DIBF_MIX(44, 9, 1, W) DIBF_MIX(46, 12, 0, W) DIBF_MIX(46, 13, 1, W)
+#define DIBF_READ(base, OFF, P1, P2, P3)                                                                      \
+  "v_mad_u32_u16 v48, " OFF ", 1, %19\n\t"                                                                    \
+  "ds_read_b64 v[" #base ":" #base "+1], v48\n\tds_read_b64 v[" #base "+2:" #base "+3], v48 offset:" P1 "\n\t"  \
+  "ds_read_b64 v[" #base "+4:" #base "+5], v48 offset:" P2 "\n\tds_read_b64 v[" #base "+6:" #base "+7], v48 offset:" P3 "\n\t"
+#define DIBF_READH(base, OFF, P1, P2, P3)                                                                     \
+  "v_mad_u32_u16 v48, " OFF ", 1, %19\n\t"                                                                    \
+  "ds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+2], v48 offset:" P1 "\n\t"                         \
+  "ds_read_b32 v[" #base "+4], v48 offset:" P2 "\n\tds_read_b32 v[" #base "+6], v48 offset:" P3 "\n\t"
+#define DIBF_RD_S(base, OFF) DIBF_READ(base, OFF, "448", "896", "1344")
+#define DIBF_RD_L(base, OFF) DIBF_READ(base, OFF, "768", "1536", "2304")
+#define DIBF_RDH_S(base, OFF) DIBF_READH(base, OFF, "448", "896", "1344")
+#define DIBF_RDH_L(base, OFF) DIBF_READH(base, OFF, "768", "1536", "2304")
+#define DIBF_LOAD(PAIR) "s_load_dwordx2 " PAIR ", %18, %16\n\ts_add_u32 %16, %16, 8\n\t"
+#define DIBF_NEXT(LABEL) "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc1 " LABEL "\n\t"
+template <bool HALF, bool L>
+__device__ __forceinline__ void tap_loop_quad_fp32(float (&acc)[16], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
+#define DIB_RF_ASM(RD, ARITH_X, ARITH_Y) \
+  asm volatile( \
+      DIBF_LOAD("s[36:37]") DIBF_LOAD("s[38:39]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(32, "s36") \
+      "Ldibf_loop%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBF_LOAD("s[40:41]") RD(40, "s37") ARITH_X("s36") DIBF_NEXT("Ldibf_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s38") ARITH_Y("s37") DIBF_NEXT("Ldibf_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBF_LOAD("s[36:37]") RD(40, "s39") ARITH_X("s38") DIBF_NEXT("Ldibf_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s40") ARITH_Y("s39") DIBF_NEXT("Ldibf_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" DIBF_LOAD("s[38:39]") RD(40, "s41") ARITH_X("s40") DIBF_NEXT("Ldibf_done%=") \
+      "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s36") ARITH_Y("s41") \
+      "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc0 Ldibf_loop%=\n\t" \
+      "Ldibf_done%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)" \
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), \
+        "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]), "+s"(toff), "+s"(cnt) \
+      : "s"(ltaps), "v"(lane_addr) \
+      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", \
+        "s36", "s37", "s38", "s39", "s40", "s41", "scc", "memory")
+  if constexpr (L && HALF) { DIB_RF_ASM(DIBF_RDH_L, DIBF_ROWSH_X, DIBF_ROWSH_Y); }
+  else if constexpr (L) { DIB_RF_ASM(DIBF_RD_L, DIBF_ROWS_X, DIBF_ROWS_Y); }
+  else if constexpr (HALF) { DIB_RF_ASM(DIBF_RDH_S, DIBF_ROWSH_X, DIBF_ROWSH_Y); }
+  else { DIB_RF_ASM(DIBF_RD_S, DIBF_ROWS_X, DIBF_ROWS_Y); }
+#undef DIB_RF_ASM
+}
+
 // STEP (the blur step's single launch, blur_step_f16_kernel): with `early` set the segment count and the first segment come
 // from the caller (the compaction's early record: the table itself must not be touched yet) and `wait_tables()` is called
 // once, between the first window's barrier and the first tap loop -- the first reader of the table's offsets.
 struct NoWait { __device__ void operator()() const {} };
+// LDS byte address of a __shared__ array (the tile function takes the integer: with a generic pointer to LDS handed through the
+// call hipcc 7.2 emitted an illegal null test in some instantiations: "V_CMP_NE_U32_e32 0, $src_shared_base")
+__device__ __forceinline__ unsigned lds_addr(unsigned *shared) { return (unsigned)(size_t)(__attribute__((address_space(3))) char *)shared; }
 template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait>
 __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
-                                                   unsigned *lds, const int wave, const int early = 0, const int nsegs0 = 0,
+                                                   const unsigned lds0, const int wave, const int early = 0, const int nsegs0 = 0,
                                                    const uint4 seg0 = uint4{0, 0, 0, 0}, const Wait wait_tables = Wait()) {
 #pragma clang fp contract(off)
   constexpr int GQ = QGeom<L>::GQ;            // LDS rows a wave fills (11; large window: 15)
@@ -599,12 +660,17 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     nsegs = nsegs0 | 1 << 30;       // bit 30: "wait for the tables in front of the first tap loop" (no register of its own)
     seg = seg0;
   } else {
-    unsigned __int128 r;
-    asm volatile("s_load_dword %0, %2, 0x1c\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(nsegs), "=&s"(r) : "s"((unsigned long long)tab), "s"((unsigned long long)segs));
+    // header words 4..7 in one request (cmax, K | geometry << 16, sum, segment count) next to the first segment
+    unsigned __int128 r, hd;
+    asm volatile("s_load_dwordx4 %0, %2, 0x10\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(hd), "=&s"(r) : "s"((unsigned long long)tab), "s"((unsigned long long)segs));
     seg = make_uint4((unsigned)r, (unsigned)(r >> 32), (unsigned)(r >> 64), (unsigned)(r >> 96));
+    nsegs = (int)(unsigned)(hd >> 96);
+    // a table compacted for the other window geometry (include/dib.h: DIB_COMPACT_LARGE_WINDOW / DIB_WINDOW_LARGE must agree)
+    // holds offsets for another LDS pitch: garbage pixels, silently.  Stop instead (the launch fails: hipErrorLaunchFailure).
+    if (((unsigned)(hd >> 32) >> 16) != (L ? 1u : 0u)) __builtin_trap();
   }
-  static_assert(HDR_NSEGS * 4 == 0x1c, "offset of the segment count in the asm above");
+  static_assert(HDR_NSEGS == 7 && HDR_K == 5 && HDR_WORDS == 8, "header words 4..7 in the asm above");
   const unsigned long long la = (unsigned long long)(tab + table_ltaps_q_off(K));
   const unsigned long long ltaps = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
                                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
@@ -615,9 +681,11 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   auto y0f = [&]() -> int { if constexpr (STEP) { int p = pxy; asm volatile("" : "+s"(p)); return (int)((unsigned)p >> 16) * TH; } else return y0c; };
   const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(d.in, ch, H, W);
   h2 acc[8];
+  float acc32[16];       // DIB_ACC_FP32: row i, column j + 32 m at [4 i + m]
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = h2{0, 0};
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc32[i] = 0.f;
   const int qb = wave * GQ;
   // Lane-derived values of the later phases are recomputed there from an opaque copy of the lane index (2-3 instructions):
   // hoisted to here they would stay live across the 44 outstanding window loads and spill (64 registers = 8 waves / SIMD).
@@ -634,7 +702,12 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     // ---- fill: per LDS row the four values P[lane + 32 m] of element `lane` (large window: six values -- element 64 + lane,
     // owned by lanes 0-31, is {P[lane + 64], P[lane + 96], P[lane + 128], P[lane + 160]}, the first two shared with element lane)
     constexpr int NK = L ? 6 : 4;
-    short v[GQ][NK];
+    // DIB_ACC_FP32 (sixteen fp32 accumulators instead of eight packed ones) fills in TWO parts of six and five rows: with all
+    // 44 values of a fill in flight next to the accumulators the kernel needs 73 registers, i.e. six waves per SIMD instead of
+    // eight (42.5 us on the BASELINE batch against 33 us for the same arithmetic volume in FMA16 mode: slots are what hide a
+    // workgroup's phases behind the others').
+    constexpr int PARTS = (ACC == DIB_ACC_FP32 && !L) ? 2 : 1, GP = (GQ + PARTS - 1) / PARTS;
+    short v[GP][NK];
     unsigned coff[NK];
     int soff[GQ];
     unsigned zmask = 0;
@@ -666,58 +739,65 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
         soff[g] = sr * w2;
       }
     }
-#pragma unroll
-    for (int g = 0; g < GQ; ++g) {
-      const int so = __builtin_amdgcn_readfirstlane(soff[g]);
-#pragma unroll
-      for (int k = 0; k < NK; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
-    }
-    if (sg > 0) __syncthreads();  // every wave is done reading the previous window
-    // Elements 0 .. 31 + column extent are read by the taps; writing all 56 of a row costs the same (an LDS store is
-    // priced per instruction), lanes 56-63 own no element.  The two 16-bit values of a word are merged by v_perm_b32
-    // straight from the load registers (the packing does not care what their high halves hold).
     const bool masked = __builtin_amdgcn_ballot_w64(zmask != 0) != 0;   // PAD_ZERO images only
-    const int wl = fresh_lane();
-    const unsigned wp = lds0 + (unsigned)(qb * QPITCH + wl * 8);
-    if constexpr (L) {     // elements lane (all lanes) and 64 + lane (lanes 0-31); zero-fill flags applied per value
 #pragma unroll
-      for (int g = 0; g < GQ; ++g) {
-        unsigned u[NK];
+    for (int part = 0; part < PARTS; ++part) {
 #pragma unroll
-        for (int k = 0; k < NK; ++k)
-          u[k] = (masked && (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u))) ? 0u : (unsigned)(unsigned short)v[g][k];
-        lds_u2v e;
-        e.x = u[0] | (u[1] << 16);
-        e.y = u[2] | (u[3] << 16);
-        *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
-        if (wl < 32) {
-          lds_u2v f;
-          f.x = u[2] | (u[3] << 16);
-          f.y = u[4] | (u[5] << 16);
-          *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH + 512)) = f;
-        }
+      for (int g = 0; g < GP; ++g) {
+        if (part * GP + g >= GQ) continue;
+        const int so = __builtin_amdgcn_readfirstlane(soff[part * GP + g]);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
       }
-    } else if (wl < QUAD_PITCH) {
-      if (!masked) {
+      if (part == 0 && sg > 0) __syncthreads();  // every wave is done reading the previous window
+      // Elements 0 .. 31 + column extent are read by the taps; writing all 56 of a row costs the same (an LDS store is
+      // priced per instruction), lanes 56-63 own no element.  The two 16-bit values of a word are merged by v_perm_b32
+      // straight from the load registers (the packing does not care what their high halves hold).
+      const int wl = fresh_lane();
+      const unsigned wp = lds0 + (unsigned)((qb + part * GP) * QPITCH + wl * 8);
+      if constexpr (L) {     // elements lane (all lanes) and 64 + lane (lanes 0-31); zero-fill flags applied per value
 #pragma unroll
-        for (int g = 0; g < GQ; ++g) {
-          lds_u2v e;
-          typedef short s2v __attribute__((ext_vector_type(2)));
-          e.x = __builtin_bit_cast(unsigned, s2v{v[g][0], v[g][1]});
-          e.y = __builtin_bit_cast(unsigned, s2v{v[g][2], v[g][3]});
-          *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
-        }
-      } else {
+        for (int g = 0; g < GP; ++g) {
+          if (part * GP + g >= GQ) continue;
+          unsigned u[NK];
 #pragma unroll
-        for (int g = 0; g < GQ; ++g) {
-          unsigned u[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            u[k] = (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u)) ? 0u : (unsigned)(unsigned short)v[g][k];
+          for (int k = 0; k < NK; ++k)
+            u[k] = (masked && (((zmask >> k) & 1u) || ((zmask >> (8 + part * GP + g)) & 1u))) ? 0u : (unsigned)(unsigned short)v[g][k];
           lds_u2v e;
           e.x = u[0] | (u[1] << 16);
           e.y = u[2] | (u[3] << 16);
           *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
+          if (wl < 32) {
+            lds_u2v f;
+            f.x = u[2] | (u[3] << 16);
+            f.y = u[4] | (u[5] << 16);
+            *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH + 512)) = f;
+          }
+        }
+      } else if (wl < QUAD_PITCH) {
+        if (!masked) {
+#pragma unroll
+          for (int g = 0; g < GP; ++g) {
+            if (part * GP + g >= GQ) continue;
+            lds_u2v e;
+            typedef short s2v __attribute__((ext_vector_type(2)));
+            e.x = __builtin_bit_cast(unsigned, s2v{v[g][0], v[g][1]});
+            e.y = __builtin_bit_cast(unsigned, s2v{v[g][2], v[g][3]});
+            *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < GP; ++g) {
+            if (part * GP + g >= GQ) continue;
+            unsigned u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              u[k] = (((zmask >> k) & 1u) || ((zmask >> (8 + part * GP + g)) & 1u)) ? 0u : (unsigned)(unsigned short)v[g][k];
+            lds_u2v e;
+            e.x = u[0] | (u[1] << 16);
+            e.y = u[2] | (u[3] << 16);
+            *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
+          }
         }
       }
     }
@@ -725,8 +805,17 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     if constexpr (STEP) { if (sg == 0 && (nsegs >> 30)) wait_tables(); }
     const int tl = fresh_lane();
     const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
-    if (W - x0f() <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true, L>(acc, ltaps, w.t0, w.n, lane_addr);
-    else tap_loop_quad<ACC == DIB_ACC_FMA16, false, L>(acc, ltaps, w.t0, w.n, lane_addr);
+    if constexpr (ACC == DIB_ACC_FP32) {
+      if (W - x0f() <= 64) tap_loop_quad_fp32<true, L>(acc32, ltaps, w.t0, w.n, lane_addr);
+      else tap_loop_quad_fp32<false, L>(acc32, ltaps, w.t0, w.n, lane_addr);
+    } else {
+      if (W - x0f() <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true, L>(acc, ltaps, w.t0, w.n, lane_addr);
+      else tap_loop_quad<ACC == DIB_ACC_FMA16, false, L>(acc, ltaps, w.t0, w.n, lane_addr);
+    }
+  }
+  if constexpr (ACC == DIB_ACC_FP32) {      // the one rounding of this mode
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = h2{(_Float16)acc32[2 * i], (_Float16)acc32[2 * i + 1]};
   }
   // ---- store: a store instruction writes 32 columns of row y (lanes 0-31) and of row y + 4 (lanes 32-63); lanes
   // outside the image get an out-of-range buffer offset and are dropped by the range check ----------------------------
@@ -807,7 +896,7 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch) 
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
   const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, nlds, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
+  blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, lds_addr(nlds), __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
 #ifdef DIB_TIMELINE
   if (threadIdx.x == 0) {
     unsigned long long *tl = DIB_TL_SLOT;
@@ -919,9 +1008,9 @@ __global__ __launch_bounds__(256, 8) void blur_step_f16_kernel(BlurBatch batch, 
 #ifdef DIB_STEP_STAMPS
       unsigned long long *dbg = *(unsigned long long *volatile *)&g_step_stamps;
       if (dbg) dbg += 8 * blockIdx.x;
-      compact_psf_f16_wg256<true, true>(psfs.p[blockIdx.x], sy.flags, sy.tables + (size_t)blockIdx.x * table_words(K), nlds, wave, rec, sy.target, dbg);
+      compact_psf_f16_wg256<true, true>(psfs.p[blockIdx.x], sy.flags, sy.tables + (size_t)blockIdx.x * table_words(K), (lds_u32 *)nlds, wave, rec, sy.target, dbg);
 #else
-      compact_psf_f16_wg256<true, true>(psfs.p[blockIdx.x], sy.flags, sy.tables + (size_t)blockIdx.x * table_words(K), nlds, wave, rec, sy.target);
+      compact_psf_f16_wg256<true, true>(psfs.p[blockIdx.x], sy.flags, sy.tables + (size_t)blockIdx.x * table_words(K), (lds_u32 *)nlds, wave, rec, sy.target);
 #endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its sc1 stores have left
       __syncthreads();
@@ -986,13 +1075,32 @@ __global__ __launch_bounds__(256, 8) void blur_step_f16_kernel(BlurBatch batch, 
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
   const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  blur_quad_tile_f16<ACC, false, true>(d, d.tab, K, ch, tx, ty, nlds, wave, early, nsegs0, seg0, StepWait{(unsigned)(size_t)(__attribute__((address_space(3))) char *)nlds + QLDS_BYTES});
+  blur_quad_tile_f16<ACC, false, true>(d, d.tab, K, ch, tx, ty, lds_addr(nlds), wave, early, nsegs0, seg0, StepWait{(unsigned)(size_t)(__attribute__((address_space(3))) char *)nlds + QLDS_BYTES});
 #ifdef DIB_STEP_STAMPS
   if (bdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bdbg[2] = __builtin_amdgcn_s_memrealtime(); }
 #endif
   // A hard end: hipcc otherwise funnels every exit through one block placed behind the compaction code and keeps values of
   // this path alive for it across the tile function, whose window fill has no register to spare (a spill to scratch memory).
   __builtin_amdgcn_endpgm();
+}
+
+// DIB_ACC_FP32 on the default tiles: the same kernel with sixteen fp32 accumulators per lane instead of eight packed ones (the
+// window fill goes in two parts to stay inside 64 registers: see the tile function).  Half the vector-ALU work of the bit-exact
+// mode per pixel and tap.
+template <int KC>
+__global__ __launch_bounds__(256, 8) void blur_quad_f32acc_kernel(BlurBatch batch) {
+  constexpr int K = KC;
+  extern __shared__ unsigned nlds[];
+  const ImageDesc d = batch.img[blockIdx.y];
+  asm volatile("" ::"s"(d.in), "s"(d.out), "s"(d.C), "s"(d.H), "s"(d.W), "s"(d.table), "s"(d.tiles_x), "s"(d.tiles_y),
+               "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab));
+  const int per_ch = d.tiles_x * d.tiles_y;
+  int local;
+  if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
+  const int ch = magic_div(local, d.inv_per_ch);
+  local -= ch * per_ch;
+  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
+  blur_quad_tile_f16<DIB_ACC_FP32>(d, d.tab, K, ch, tx, ty, lds_addr(nlds), __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
 }
 
 // The same tile function on the LARGE window (39.9 KB of LDS: 4 workgroups per CU, so up to 128 registers per lane cost
@@ -1008,7 +1116,7 @@ __global__ __launch_bounds__(256, 4) void blur_quad_large_f16_kernel(BlurBatch b
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
   const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  blur_quad_tile_f16<ACC, true>(d, d.tab, K, ch, tx, ty, nlds, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
+  blur_quad_tile_f16<ACC, true>(d, d.tab, K, ch, tx, ty, lds_addr(nlds), __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
 }
 
 template <int ACC>
@@ -1140,6 +1248,8 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 256>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f32acc_kernel<128>), QLDS_BYTES));
+    DIB_HIP_CHECK(opt_in((blur_quad_f32acc_kernel<256>), QLDS_BYTES));
     DIB_HIP_CHECK(opt_in((blur_step_f16_kernel<DIB_ACC_BITEXACT>), QLDS_BYTES + STEP_LDS_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_step_f16_kernel<DIB_ACC_FMA16>), QLDS_BYTES + STEP_LDS_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_large_f16_kernel<DIB_ACC_BITEXACT, 128>), QGeom<true>::BYTES));
@@ -1285,7 +1395,7 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   int i = 0;
   while (i < B) {
     BlurBatch tiled, generic;
-    const bool quad = g_shape == 0 && dtype == DIB_F16 && acc_mode != DIB_ACC_FP32;
+    const bool quad = g_shape == 0 && dtype == DIB_F16;
     tiled.n = generic.n = 0;
     int tiles = 0, gblocks = 0;
     for (; i < B && tiled.n < MAX_BATCH; ++i) {
@@ -1337,6 +1447,8 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     else hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 256>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled);          \
   } while (0)
       if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_QUAD(DIB_ACC_FMA16);
+      else if (quad && acc_mode == DIB_ACC_FP32 && K == 128) hipLaunchKernelGGL((blur_quad_f32acc_kernel<128>), grid, dim3(256), QLDS_BYTES, s, tiled);
+      else if (quad && acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_quad_f32acc_kernel<256>), grid, dim3(256), QLDS_BYTES, s, tiled);
       else if (quad) DIB_LAUNCH_QUAD(DIB_ACC_BITEXACT);
 #undef DIB_LAUNCH_QUAD
       else if (acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_tiled_f16_kernel<DIB_ACC_FP32>), grid, dim3(256), LDS_BYTES, s, tiled, (const int *)tables_dev, K, g_stamp_buffer);

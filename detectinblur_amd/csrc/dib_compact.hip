@@ -227,7 +227,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   if (normalize & COMPACT_NO_SEGMENTS) return;  // diagnostics: skip the segmentation
 
   // ---- segmentation (wave 0): dib_compact_dev.h ----
-  segment_taps<false, STAGE_TAPS>(tab, K, normalize, ntaps, s_rc, s_wb, lane);
+  segment_taps<false, STAGE_TAPS>(tab, K, normalize, ntaps, (const lds_u16 *)s_rc, (const lds_u32 *)s_wb, lane);
 }
 
 }  // namespace dib
@@ -300,7 +300,7 @@ extern "C" int dib_psf_compact_list(const void *const *psf_ptrs, int dtype, int 
 namespace dib {
 __global__ __launch_bounds__(256, 8) void psf_compact_wg256_kernel(PsfPtrs ptrs, int flags, int *__restrict__ tables) {
   extern __shared__ unsigned pool[];
-  compact_psf_f16_wg256<true>(ptrs.p[blockIdx.x], flags, tables + (size_t)blockIdx.x * table_words(128), pool, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
+  compact_psf_f16_wg256<true>(ptrs.p[blockIdx.x], flags, tables + (size_t)blockIdx.x * table_words(128), (lds_u32 *)pool, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
 }
 }  // namespace dib
 extern "C" int dib_debug_compact_wg256(const void *const *psf_ptrs, int B, int normalize, void *tables_dev, void *stream) {

@@ -145,17 +145,22 @@ template <bool WT> __device__ __forceinline__ void st128(void *p, unsigned a, un
   else *(uint4 *)p = make_uint4(a, b, c, d);
 }
 
-// An `int` in LDS, named by its LDS address: the first-segment words travel to the segmenters this way.  (As a generic pointer
-// into the step kernel's LDS, hipcc 7.2 died on it: "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base".)
+// LDS memory is named by pointers of the LDS address space throughout the compaction's device code.  (Generic pointers into the
+// step kernel's dynamic LDS made hipcc 7.2 die now and then, depending on unrelated code: "Illegal instruction detected:
+// V_CMP_NE_U32_e32 0, $src_shared_base" -- the null test of an address-space cast it failed to fold.)
 typedef __attribute__((address_space(3))) int lds_int;
-__device__ __forceinline__ lds_int *lds_ptr(int *generic) { return (lds_int *)(size_t)(unsigned)(size_t)generic; }
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(3))) unsigned short lds_u16;
+typedef __attribute__((address_space(3))) long long lds_i64;
+typedef unsigned lds_vec4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) lds_vec4 lds_u128;
 
 // ---- segmentation (ONE wave): greedy runs with row span <= SEG_ROWS and column span <= SEG_COLS -----------------------------
 // Cuts the row-major tap list into the segments the tiled blur stages in LDS and writes, per tap, its source offset inside
 // that window for both window layouts (ltaps / ltaps_q), the 8 zero words behind them and HDR_NSEGS.  The first STAGE taps are
 // read from LDS (s_rc = row << 8 | col, s_wb = weight bits), later ones from the table's own tap list.
 template <bool WT, int STAGE, bool FIRST = false>   // FIRST: s_first (LDS, 5 words) receives the first entry and the count, as segment_positions leaves them
-__device__ __forceinline__ void segment_taps(int *tab, int K, int flags, int ntaps, const unsigned short *s_rc, const unsigned *s_wb, int lane,
+__device__ __forceinline__ void segment_taps(int *tab, int K, int flags, int ntaps, const lds_u16 *s_rc, const lds_u32 *s_wb, int lane,
                                               lds_int *s_first = nullptr) {
   const uint2 *taps = reinterpret_cast<const uint2 *>(tab + table_taps_off(K));
   char *segs = reinterpret_cast<char *>(tab + table_segs_off(K));
@@ -233,8 +238,8 @@ __device__ __forceinline__ void segment_taps(int *tab, int K, int flags, int nta
 // writes the segment entries and HDR_NSEGS and leaves, in LDS, every tap's segment (s_seg) and every segment's
 // r_last << 8 | cmax (s_sinfo), from which all threads then form the per-tap offsets at once.
 template <bool WT>
-__device__ __forceinline__ void segment_positions(int *tab, int K, int flags, int ntaps, const unsigned short *s_rc, unsigned short *s_seg,
-                                                   unsigned *s_sinfo, lds_int *s_first, int lane) {
+__device__ __forceinline__ void segment_positions(int *tab, int K, int flags, int ntaps, const lds_u16 *s_rc, lds_u16 *s_seg,
+                                                   lds_u32 *s_sinfo, lds_int *s_first, int lane) {
   char *segs = reinterpret_cast<char *>(tab + table_segs_off(K));
   const bool large = (flags & COMPACT_LARGE_WINDOW) != 0;
   const int seg_rows = large ? SEG_ROWS_L : SEG_ROWS, seg_cols = large ? SEG_COLS_L : SEG_COLS;
@@ -312,19 +317,19 @@ constexpr int CSTAGE = 1024, CHITS = 512;
 // (A template flag, not a null test of the pointer: hipcc 7.2 miscompiled that test inside the step kernel -- "Illegal instruction
 // detected: V_CMP_NE_U32_e32 0, $src_shared_base".)
 template <bool WT, bool EARLY = false>
-__device__ __forceinline__ void compact_psf_f16_wg256(const void *psf, int flags, int *tab, unsigned *pool, const int wave, unsigned *early = nullptr,
+__device__ __forceinline__ void compact_psf_f16_wg256(const void *psf, int flags, int *tab, lds_u32 *pool, const int wave, unsigned *early = nullptr,
                                                       unsigned tag = 0, unsigned long long *dbg = nullptr) {
 #define DIB_CSTAMP(n) do { if (dbg && wave == 0 && lane == 0) dbg[n] = __builtin_amdgcn_s_memrealtime(); } while (0)
   using E = Elem<__half>;
   constexpr int K = 128, LK = 7, NCH = K * K / 8 / 256;   // 8 pieces of 16 bytes per thread
-  unsigned short *s_rc = reinterpret_cast<unsigned short *>(pool);            // [CSTAGE]   row << 8 | col
-  unsigned *s_wb = pool + CSTAGE / 2;                                          // [CSTAGE]   weight bits
-  uint4 *s_hit = reinterpret_cast<uint4 *>(pool + CSTAGE / 2 + CSTAGE);        // [CHITS]    pieces that hold a non-zero
-  unsigned *s_hmeta = pool + CSTAGE / 2 + CSTAGE + 4 * CHITS;                  // [CHITS]    mask | offset inside the pair << 8 | tid << 18 | i << 26
-  int *s_tot = reinterpret_cast<int *>(s_hmeta + CHITS);                       // [NCH * 4]  non-zeros of (piece i, wave w), at i * 4 + w
-  int *s_base = s_tot + NCH * 4;                                               // [NCH * 4]  exclusive prefix of s_tot
-  long long *s_part = reinterpret_cast<long long *>(s_base + NCH * 4);         // [4]
-  int *s_misc = reinterpret_cast<int *>(s_part + 4);                           // [16] 0: a tap vanished, 1: taps kept, 2..5: extents, 6: pieces listed, 7: the sum's bits, 8..11: first segment, 12: segments
+  lds_u16 *s_rc = (lds_u16 *)pool;                                             // [CSTAGE]   row << 8 | col
+  lds_u32 *s_wb = pool + CSTAGE / 2;                                           // [CSTAGE]   weight bits
+  lds_u128 *s_hit = (lds_u128 *)(pool + CSTAGE / 2 + CSTAGE);                  // [CHITS]    pieces that hold a non-zero
+  lds_u32 *s_hmeta = pool + CSTAGE / 2 + CSTAGE + 4 * CHITS;                   // [CHITS]    mask | offset inside the pair << 8 | tid << 18 | i << 26
+  lds_int *s_tot = (lds_int *)(s_hmeta + CHITS);                               // [NCH * 4]  non-zeros of (piece i, wave w), at i * 4 + w
+  lds_int *s_base = s_tot + NCH * 4;                                             // [NCH * 4]  exclusive prefix of s_tot
+  lds_i64 *s_part = (lds_i64 *)(s_base + NCH * 4);                         // [4]
+  lds_int *s_misc = (lds_int *)(s_part + 4);                                   // [16] 0: a tap vanished, 1: taps kept, 2..5: extents, 6: pieces listed, 7: the sum's bits, 8..11: first segment, 12: segments
   static_assert(((CSTAGE / 2 + CSTAGE) * 4) % 16 == 0 && ((CSTAGE / 2 + CSTAGE + 5 * CHITS + 2 * NCH * 4) * 4) % 8 == 0, "alignment of s_hit / s_part");
   static_assert((CSTAGE / 2 + CSTAGE + 5 * CHITS + 2 * NCH * 4 + 8 + 16) * 4 <= 19712, "fits the blur's window");
   const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -369,8 +374,8 @@ __device__ __forceinline__ void compact_psf_f16_wg256(const void *psf, int flags
       if (__builtin_amdgcn_ballot_w64(b != 0) != 0) {
         incl = wave_scan_incl_i32(c, lane);
         if (b) {
-          const int slot = atomicAdd(&s_misc[6], 1);
-          if (slot < CHITS) { s_hit[slot] = q[i]; s_hmeta[slot] = b | (unsigned)(incl - c) << 8 | (unsigned)tid << 18 | (unsigned)i << 26; }
+          const int slot = __hip_atomic_fetch_add(&s_misc[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (slot < CHITS) { s_hit[slot] = lds_vec4{q[i].x, q[i].y, q[i].z, q[i].w}; s_hmeta[slot] = b | (unsigned)(incl - c) << 8 | (unsigned)tid << 18 | (unsigned)i << 26; }
         }
       }
       if (lane == 63) s_tot[i * 4 + wave] = incl;
@@ -386,7 +391,7 @@ __device__ __forceinline__ void compact_psf_f16_wg256(const void *psf, int flags
   if (ok) {
     if (lane < NCH * 4) s_base[lane] = tincl - tv;     // every wave writes the same 32 values and reads back its own
     for (int h = tid; h < nhits; h += 256) {
-      const uint4 v = s_hit[h];
+      const lds_vec4 v = s_hit[h];
       const unsigned m = s_hmeta[h];
       const int i = m >> 26, t = (m >> 18) & 255;
       int pos = s_base[i * 4 + (t >> 6)] + (int)((m >> 8) & 1023);
@@ -406,8 +411,8 @@ __device__ __forceinline__ void compact_psf_f16_wg256(const void *psf, int flags
   // ---- C: three things that do not need each other, on three waves: wave 0 cuts the (raw) tap POSITIONS into segments,
   // wave 1 forms the exact sum, waves 2 / 3 have nothing yet.  (One after the other on the whole workgroup these phases were
   // 2.4 us of the 6.5 us the blur's workgroups waited for this one: profiles/r5_step_timeline.txt.)
-  unsigned short *s_seg = reinterpret_cast<unsigned short *>(s_hit);           // [CSTAGE] segment of tap j   (the piece list is dead)
-  unsigned *s_sinfo = reinterpret_cast<unsigned *>(s_seg + CSTAGE);            // [CSTAGE] r_last << 8 | cmax of segment s
+  lds_u16 *s_seg = (lds_u16 *)s_hit;                                           // [CSTAGE] segment of tap j   (the piece list is dead)
+  lds_u32 *s_sinfo = (lds_u32 *)(s_seg + CSTAGE);                              // [CSTAGE] r_last << 8 | cmax of segment s
   static_assert(CSTAGE * 2 + CSTAGE * 4 <= CHITS * 16, "segment ids + infos fit the piece list's space");
   __half total = __float2half_rn(1.0f);
   // the first segment's record (wave 0, which wrote s_misc[8..12] itself: no barrier in between)
@@ -434,7 +439,7 @@ __device__ __forceinline__ void compact_psf_f16_wg256(const void *psf, int flags
     if (lane == 0) { s_misc[4] = cmn; s_misc[5] = cmx; }
   };
   if (ok) {
-    if (wave == 0 && !(flags & COMPACT_NO_SEGMENTS)) segment_positions<WT>(tab, K, flags, n_raw, s_rc, s_seg, s_sinfo, lds_ptr(s_misc + 8), lane);
+    if (wave == 0 && !(flags & COMPACT_NO_SEGMENTS)) segment_positions<WT>(tab, K, flags, n_raw, s_rc, s_seg, s_sinfo, s_misc + 8, lane);
     if (wave == 1) {   // the exact sum, then every weight divided by it (in place): a tap whose weight becomes zero vanishes
       bool lost = false, sane = true;
       if (normalize) {
@@ -492,7 +497,7 @@ __device__ __forceinline__ void compact_psf_f16_wg256(const void *psf, int flags
       __syncthreads();
       ntaps = s_misc[1];
       // segments, row pointers and extents were made with the vanished taps in them: once more
-      if (wave == 0 && !(flags & COMPACT_NO_SEGMENTS)) { segment_taps<WT, CSTAGE, true>(tab, K, flags, ntaps, s_rc, s_wb, lane, lds_ptr(s_misc + 8)); publish_first(); }
+      if (wave == 0 && !(flags & COMPACT_NO_SEGMENTS)) { segment_taps<WT, CSTAGE, true>(tab, K, flags, ntaps, s_rc, s_wb, lane, s_misc + 8); publish_first(); }
       if (wave == 1) col_extents(ntaps);
       if (wave >= 2) {
         row_pointers((wave - 2) * 64 + lane, ntaps);
@@ -575,7 +580,10 @@ __device__ __forceinline__ void compact_psf_f16_wg256(const void *psf, int flags
       if (lane == 63) s_tot[i * 4 + wave] = sc;
     }
     rmin = wave_min_i32(rmin); rmax = wave_max_i32(rmax); cmin = wave_min_i32(cmin); cmax = wave_max_i32(cmax);
-    if (lane == 0) { atomicMin(&s_misc[2], rmin); atomicMax(&s_misc[3], rmax); atomicMin(&s_misc[4], cmin); atomicMax(&s_misc[5], cmax); }
+    if (lane == 0) {
+      __hip_atomic_fetch_min(&s_misc[2], rmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_max(&s_misc[3], rmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_min(&s_misc[4], cmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_max(&s_misc[5], cmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     __syncthreads();
     tv = lane < NCH * 4 ? s_tot[lane] : 0;
     tincl = wave_scan_incl_i32(tv, lane);
@@ -612,7 +620,7 @@ __device__ __forceinline__ void compact_psf_f16_wg256(const void *psf, int flags
     __threadfence_block();
     __syncthreads();
   }
-  if (wave == 0 && !(flags & COMPACT_NO_SEGMENTS)) { segment_taps<WT, CSTAGE, true>(tab, K, flags, ntaps, s_rc, s_wb, lane, lds_ptr(s_misc + 8)); publish_first(); }
+  if (wave == 0 && !(flags & COMPACT_NO_SEGMENTS)) { segment_taps<WT, CSTAGE, true>(tab, K, flags, ntaps, s_rc, s_wb, lane, s_misc + 8); publish_first(); }
 #undef DIB_CSTAMP
 }
 

@@ -72,6 +72,13 @@ extern "C" int dib_blur_step(const void *const *psf_ptrs, int psf_dtype, int num
   }
   int dev = 0;
   DIB_HIP_CHECK(hipGetDevice(&dev));
+  if (s) {   // the table buffers are allocated on the CURRENT device: a stream of another one would launch on memory it cannot reach
+    hipDevice_t sdev = dev;
+    if (hipStreamGetDevice(s, &sdev) == hipSuccess && (int)sdev != dev) {
+      set_error("dib_blur_step: `stream` belongs to device %d, the current device is %d (hipSetDevice first)", (int)sdev, dev);
+      return DIB_EINVAL;
+    }
+  }
   std::lock_guard<std::mutex> lock(g_step_mutex);
   StepState &st = g_step[key_of(dev, s)];
   Slot &sl = st.slot[st.next & 1];

@@ -222,7 +222,7 @@ extern "C" int dib_topk_levels(const float *values_dev, long long row_stride, in
     if (level_offset[l + 1] < level_offset[l] || level_k[l] < 0 || level_k[l] > K) { set_error("dib_topk_levels: bad level %d", l); return DIB_EINVAL; }
     lv.k[l] = level_k[l];
   }
-  if (level_offset[L] - level_offset[0] > row_stride) { set_error("dib_topk_levels: levels longer than a row"); return DIB_EINVAL; }
+  if (level_offset[0] < 0 || level_offset[L] > row_stride) { set_error("dib_topk_levels: the levels [%d, %d) do not lie inside a row of %lld", level_offset[0], level_offset[L], row_stride); return DIB_EINVAL; }
   if (N == 0) return DIB_OK;
   if (!values_dev || !out_scores_dev || ((out_boxes_dev || out_valid_dev) && !boxes_dev)) { set_error("dib_topk_levels: null pointer"); return DIB_EINVAL; }
   if ((((uintptr_t)boxes_dev | (uintptr_t)out_boxes_dev) & 15) != 0) { set_error("dib_topk_levels: boxes must be 16-byte aligned"); return DIB_EINVAL; }

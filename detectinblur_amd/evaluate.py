@@ -51,6 +51,8 @@ def _load(model, path):
 
 
 def main(args):
+    from . import kernel_choices
+    kernel_choices.use_shipped_kernel_choices()      # shipped MIOpen / TunableOp choices, private copy per process (kernel_choices.py)
     reject_out_of_scope(args)
     mp_ctx = utils.loader_context() if args.workers > 0 else None      # before anything touches the GPU (see utils.loader_context)
     utils.init_distributed_mode(args)

@@ -57,9 +57,12 @@ class GraphCache(object):
             g = self.graphs.pop(key)
             self.graphs[key] = g                    # most recently used last
             return g(x) if g is not None else self.fn(x)
-        n = self.seen[key] = self.seen.get(key, 0) + 1
+        n = self.seen[key] = self.seen.pop(key, 0) + 1                 # re-inserted: most recently seen last
+        while len(self.seen) > 64 * self.limit:                         # a varied dataset's rare shapes: forget the oldest sightings
+            self.seen.pop(next(iter(self.seen)))
         if n < self.capture_after:
             return self.fn(x)
+        self.seen.pop(key, None)                                       # captured (or failed) from here on: `graphs` remembers it
         while len(self.graphs) >= self.limit:
             self.graphs.pop(next(iter(self.graphs)))        # least recently used
         if self.pool is None:

@@ -125,7 +125,10 @@ class GeneralizedRCNN(nn.Module):
         for (boxes, scores, labels, count), size, original in zip(padded, batch.image_sizes, handle["original_sizes"]):
             k = boxes.shape[0]
             boxes = resize_boxes(boxes, size, original)                          # transform.postprocess, on the padded rows
-            slot = ring["slot"] = (ring["slot"] + 1) % 8                         # pinned rows are reused 8 images later: far beyond the pipeline's depth
+            # pinned rows are reused `depth` images later: two batches are in flight in engine.evaluate's pipeline (the heads of batch
+            # j are queued before batch j - 1 is read), so the ring holds three batches' worth, and at least 8
+            depth = ring["depth"] = max(ring.get("depth", 8), 3 * len(padded) + 2)
+            slot = ring["slot"] = (ring["slot"] + 1) % depth
             buf = ring["bufs"].get((slot, k))
             if buf is None:
                 buf = ring["bufs"][(slot, k)] = (torch.empty((k, 5), dtype=torch.float32).pin_memory(),

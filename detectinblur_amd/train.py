@@ -159,6 +159,8 @@ def log_coco_stats(writer, prefix, coco_evaluator, step):
 
 
 def main(args):
+    from . import kernel_choices
+    kernel_choices.use_shipped_kernel_choices()      # shipped MIOpen / TunableOp choices, private copy per process (kernel_choices.py)
     reject_out_of_scope(args)
     mp_ctx = utils.loader_context() if args.workers > 0 else None      # before anything touches the GPU (see utils.loader_context)
     utils.init_distributed_mode(args)
@@ -230,6 +232,7 @@ def main(args):
         ck = torch.load(args.resume, map_location="cpu", weights_only=False)
         model_without_ddp.load_state_dict(ck["model"])
         optimizer.load_state_dict(ck["optimizer"])
+        utils.restore_sgd_implementation(optimizer, getattr(args, "foreach_sgd", False))
         lr_scheduler.load_state_dict(ck["lr_scheduler"])
         args.start_epoch = ck["epoch"] + 1
     if args.start_from_weights:                                         # :260-263

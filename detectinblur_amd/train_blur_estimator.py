@@ -66,6 +66,8 @@ def build_parser():
 
 
 def main(args):
+    from . import kernel_choices
+    kernel_choices.use_shipped_kernel_choices()      # shipped MIOpen / TunableOp choices, private copy per process (kernel_choices.py)
     mp_ctx = utils.loader_context() if args.workers > 0 else None      # before anything touches the GPU (see utils.loader_context)
     utils.init_distributed_mode(args)
     print(args)

@@ -359,3 +359,17 @@ def make_sgd(params, lr, momentum, weight_decay, foreach=False):
     fused = (not foreach) and bool(params) and all(p.is_cuda and p.dtype == torch.float32 for p in params)
     kw = {"fused": True} if fused else {}
     return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, **kw)
+
+
+def restore_sgd_implementation(optimizer, foreach=False):
+    """After `optimizer.load_state_dict(...)`: a checkpoint's param_groups arrive wholesale, `fused` / `foreach` included -- a
+    reference-written checkpoint (no `fused` key) would silently switch the run to the foreach kernels, one written on the GPU
+    and resumed with the parameters on the CPU would raise in step().  The implementation is chosen again, from the parameters
+    as they are now, exactly as `make_sgd` chooses it."""
+    import torch
+    for group in optimizer.param_groups:
+        ps = group["params"]
+        fused = (not foreach) and bool(ps) and all(p.is_cuda and p.dtype == torch.float32 for p in ps)
+        group["fused"] = True if fused else None
+        group["foreach"] = None
+    return optimizer

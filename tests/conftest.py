@@ -13,8 +13,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # The DataLoader workers of the driver tests come from a fork server that must exist before this process touches the
     # GPU (detectinblur_amd.utils.loader_context: a fork of a GPU process stalls the GPU for tens of seconds).
-    from detectinblur_amd import utils
+    from detectinblur_amd import kernel_choices, utils
     utils.loader_context()
+    # the detector tests compare runs with each other and with pinned numbers: same kernel choices in every process
+    kernel_choices.use_shipped_kernel_choices()
 
 
 def pytest_collection_modifyitems(config, items):

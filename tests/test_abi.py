@@ -69,19 +69,23 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_every_process_gets_a_private_copy_of_the_shipped_miopen_find_db():
-    """`import detectinblur_amd` points MIOPEN_USER_DB_PATH at a temporary copy of detectinblur_amd/miopen_db (MIOpen appends
-    to its user db; a shared one made kernel choices drift from process to process), respects an explicit setting, and works on
-    the shipped directory itself only on request."""
+    """`detectinblur_amd.use_shipped_kernel_choices()` -- NOT the import -- points MIOPEN_USER_DB_PATH at a temporary copy of
+    detectinblur_amd/miopen_db (MIOpen appends to its user db; a shared one made kernel choices drift from process to process),
+    respects a user's explicit setting, gives a child process a copy of its own, and works on the shipped directory itself only on
+    request."""
     import subprocess
     import sys
-    code = "import os, detectinblur_amd; p = os.environ.get('MIOPEN_USER_DB_PATH'); print(p); print(sorted(os.listdir(p)) if p and os.path.isdir(p) else None)"
+    code = ("import os, detectinblur_amd; assert 'MIOPEN_USER_DB_PATH' not in os.environ or os.environ.get('DIB_TEST_PRESET'); "
+            "detectinblur_amd.use_shipped_kernel_choices(); p = os.environ.get('MIOPEN_USER_DB_PATH'); print(p); "
+            "print(sorted(os.listdir(p)) if p and os.path.isdir(p) else None)")
     shipped = os.path.join(ROOT, "detectinblur_amd", "miopen_db")
     files = sorted(f for f in os.listdir(shipped) if os.path.isfile(os.path.join(shipped, f)))
     assert files and all(f.endswith(".ufdb.txt") or f.endswith(".udb.txt") for f in files)       # find-db (+ the tuned perf-db)
     assert any(f.endswith(".ufdb.txt") for f in files)
 
     def run(extra):
-        env = {k: v for k, v in os.environ.items() if k not in ("MIOPEN_USER_DB_PATH", "DIB_MIOPEN_DB_INPLACE", "DIB_NO_MIOPEN_DB")}
+        env = {k: v for k, v in os.environ.items() if k not in ("MIOPEN_USER_DB_PATH", "DIB_MIOPEN_DB_INPLACE", "DIB_NO_MIOPEN_DB",
+                                                                "DIB_KERNEL_CHOICES_OWNER", "DIB_TEST_PRESET")}
         env.update(extra)
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -91,7 +95,10 @@ def test_every_process_gets_a_private_copy_of_the_shipped_miopen_find_db():
     path, listing = run({})
     assert path != shipped and "dib_miopen_db_" in path and listing == str(files)
     assert not os.path.exists(path)                                   # removed when the process exits
-    assert run({"MIOPEN_USER_DB_PATH": "/tmp"})[0] == "/tmp"
+    assert run({"MIOPEN_USER_DB_PATH": "/tmp", "DIB_TEST_PRESET": "1"})[0] == "/tmp"                       # the user's own setting
+    # a path exported by THIS module in a parent process (marked by its pid) is not the user's: the child makes its own copy
+    child = run({"MIOPEN_USER_DB_PATH": "/tmp/dib_miopen_db_of_a_parent", "DIB_KERNEL_CHOICES_OWNER": "1", "DIB_TEST_PRESET": "1"})
+    assert "dib_miopen_db_" in child[0] and child[0] != "/tmp/dib_miopen_db_of_a_parent" and child[1] == str(files)
     assert run({"DIB_MIOPEN_DB_INPLACE": "1"})[0] == shipped
     assert run({"DIB_NO_MIOPEN_DB": "1"})[0] == "None"
     lines = sum(1 for _ in open(os.path.join(shipped, [f for f in files if f.endswith(".ufdb.txt")][0])))
@@ -99,17 +106,17 @@ def test_every_process_gets_a_private_copy_of_the_shipped_miopen_find_db():
 
 
 def test_every_process_reads_a_private_copy_of_the_shipped_gemm_choices():
-    """`import detectinblur_amd` switches PyTorch's TunableOp to look-up-only mode on a temporary copy of
+    """`detectinblur_amd.use_shipped_kernel_choices()` switches PyTorch's TunableOp to look-up-only mode on a temporary copy of
     detectinblur_amd/tunableop/tunableop_results.csv (one per device ordinal, as PyTorch names them), respects an explicit
     PYTORCH_TUNABLEOP_ENABLED and DIB_NO_TUNABLEOP, and the shipped file carries the validators PyTorch checks before using it."""
     import subprocess
     import sys
-    code = ("import os, detectinblur_amd; e = os.environ; f = e.get('PYTORCH_TUNABLEOP_FILENAME'); "
+    code = ("import os, detectinblur_amd; detectinblur_amd.use_shipped_kernel_choices(); e = os.environ; f = e.get('PYTORCH_TUNABLEOP_FILENAME'); "
             "print(e.get('PYTORCH_TUNABLEOP_ENABLED'), e.get('PYTORCH_TUNABLEOP_TUNING'), f, "
             "len(os.listdir(os.path.dirname(f))) if f and os.path.isdir(os.path.dirname(f)) else None)")
 
     def run(extra):
-        env = {k: v for k, v in os.environ.items() if not k.startswith("PYTORCH_TUNABLEOP") and k != "DIB_NO_TUNABLEOP"}
+        env = {k: v for k, v in os.environ.items() if not k.startswith("PYTORCH_TUNABLEOP") and k not in ("DIB_NO_TUNABLEOP", "DIB_KERNEL_CHOICES_OWNER")}
         env.update(extra)
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
