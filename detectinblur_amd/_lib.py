@@ -51,6 +51,9 @@ _SIGNATURES = {
     "dib_normalize_resize_pad": (ctypes.c_int, [_c_void_pp, ctypes.c_int, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "dib_sparse_blur_normalized": (ctypes.c_int, [_c_void_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "dib_expand_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p]),
     "dib_clamp_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -142,7 +145,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.dib_abi_version() != 5:
+        if l.dib_abi_version() != 6:
             raise ImportError("libdib_hip.so ABI version mismatch")
         _lib = l
     return _lib

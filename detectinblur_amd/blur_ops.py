@@ -224,6 +224,43 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
     return outs
 
 
+def sparse_blur_normalized(images, table_index, tables, means, stds, Hp, Wp, channels_last=False, acc_mode=_lib.DIB_ACC_BITEXACT, order=None):
+    """sparse_blur + normalize_pad as ONE launch (dib_sparse_blur_normalized): the fp32 batch [B,3,Hp,Wp] holding
+    (blurred - mean) / std inside each image and 0 in the padding, or None when the library does not serve the batch that way
+    (an image with table_index < 0, a padded extent the image's tiles do not cover, the large window, ...): the caller then
+    blurs and normalises in two launches.  images: 3 x H x W float16 CUDA tensors; means / stds: [B,3] rows.  `order`: the
+    sequence in which the images are handed to the launch (heaviest PSF first lets it end on its cheapest tiles); the batch
+    position of every image stays its list position.  Bit-identical to the two launches."""
+    import ctypes
+    import numpy as np
+    B = len(images)
+    if B == 0 or tables.large:
+        return None
+    first = images[0]
+    for img in images:
+        if not (img.is_cuda and img.dtype == torch.float16 and img.dim() == 3 and img.shape[0] == 3):
+            return None
+    if any(t < 0 for t in table_index):
+        return None
+    _await(tables)
+    seq = list(order) if order is not None else list(range(B))
+    keep = [images[i] if images[i].is_contiguous() else images[i].contiguous() for i in seq]
+    m = np.ascontiguousarray(np.asarray(means, dtype=np.float64).reshape(B, 3).astype(np.float32)[seq])
+    sd = np.ascontiguousarray(np.asarray(stds, dtype=np.float64).reshape(B, 3).astype(np.float32)[seq])
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    out = torch.empty((B, 3, Hp, Wp), dtype=torch.float32, device=first.device, memory_format=fmt)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = _lib.lib().dib_sparse_blur_normalized(_lib.ptr_array([k.data_ptr() for k in keep]), _lib.int_array([int(k.shape[1]) for k in keep]),
+                                               _lib.int_array([int(k.shape[2]) for k in keep]), _lib.int_array([table_index[i] for i in seq]),
+                                               _lib.int_array(seq), B, tables.buf.data_ptr(), tables.count, tables.K, acc_mode,
+                                               m.ctypes.data_as(fp), sd.ctypes.data_as(fp), out.data_ptr(), Hp, Wp, int(bool(channels_last)),
+                                               _stream(first.device))
+    if rc == 1:
+        return None
+    _lib.check(rc)
+    return out
+
+
 def blur_step(images, table_index, psfs, normalize=True, acc_mode=_lib.DIB_ACC_BITEXACT, psfs_complete=False, large_window=False):
     """compact_psfs(psfs) + sparse_blur(images, table_index, tables) behind ONE library call (dib_blur_step), the tables
     in library-owned buffers (two per stream, alternating).  psfs: list of K x K CUDA tensors of one dtype, 16-byte

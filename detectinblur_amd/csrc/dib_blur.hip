@@ -29,6 +29,7 @@
 // eight of them per CU, and hence the instruction diet of everything outside the tap loop.
 #include "dib_compact_dev.h"
 #include <mutex>
+#include <vector>
 #include <stdlib.h>
 
 namespace dib {
@@ -638,13 +639,23 @@ __device__ __forceinline__ void tap_loop_quad_fp32(float (&acc)[16], unsigned lo
 // from the caller (the compaction's early record: the table itself must not be touched yet) and `wait_tables()` is called
 // once, between the first window's barrier and the first tap loop -- the first reader of the table's offsets.
 struct NoWait { __device__ void operator()() const {} };
+// NORM (dib_sparse_blur_normalized): the store phase writes float((blurred - mean) / std) into the detector's zero-padded fp32
+// batch (planar, or channels-last) instead of the fp16 image: the blur and dib_normalize_pad in one launch, for batches whose
+// images need no resize (reference engine.py:107-110 + models/net_transforms.py:112-121, :238-247).  Same operations in the same
+// order as the two launches (fp16 -> fp32, subtract, IEEE divide): bit-identical.
+struct NormArgs {
+  float mean[MAX_BATCH][4], std[MAX_BATCH][4];   // per image (descriptor order) and channel
+  int Hp, Wp;                                     // the batch's padded height and width: pixels outside the image become 0
+  int nhwc;                                       // 1: channels-last batch [B][Hp][Wp][3]; the launch then orders tiles channel-fastest
+};
 // LDS byte address of a __shared__ array (the tile function takes the integer: with a generic pointer to LDS handed through the
 // call hipcc 7.2 emitted an illegal null test in some instantiations: "V_CMP_NE_U32_e32 0, $src_shared_base")
 __device__ __forceinline__ unsigned lds_addr(unsigned *shared) { return (unsigned)(size_t)(__attribute__((address_space(3))) char *)shared; }
-template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait>
+template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait, bool NORM = false>
 __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
                                                    const unsigned lds0, const int wave, const int early = 0, const int nsegs0 = 0,
-                                                   const uint4 seg0 = uint4{0, 0, 0, 0}, const Wait wait_tables = Wait()) {
+                                                   const uint4 seg0 = uint4{0, 0, 0, 0}, const Wait wait_tables = Wait(),
+                                                   const NormArgs *na = nullptr, const int img = 0) {
 #pragma clang fp contract(off)
   constexpr int GQ = QGeom<L>::GQ;            // LDS rows a wave fills (11; large window: 15)
   constexpr int QPITCH = QGeom<L>::PITCH, QUAD_PITCH = QGeom<L>::PITCH_EL, LROWS = QGeom<L>::ROWS;   // shadow the standard geometry's constants
@@ -819,7 +830,32 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   }
   // ---- store: a store instruction writes 32 columns of row y (lanes 0-31) and of row y + 4 (lanes 32-63); lanes
   // outside the image get an out-of-range buffer offset and are dropped by the range check ----------------------------
-  {
+  if constexpr (NORM) {
+    const int Hp = na->Hp, Wp = na->Wp, nhwc = na->nhwc;
+    const float m = na->mean[img][ch], sd = na->std[img][ch];
+    const unsigned long long a = (unsigned long long)d.out + (nhwc ? (unsigned long long)ch * 4ull : (unsigned long long)ch * Hp * Wp * 4ull);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, Hp * Wp * 4 * (nhwc ? 3 : 1) - (nhwc ? ch * 4 : 0), 0x00020000);
+    const int x0 = x0f(), y0 = y0f();
+    const int sl = fresh_lane();
+    const int yl = y0 + wave * 8 + (sl >> 5) * 4, xl = x0 + (sl & 31);
+    const unsigned px = nhwc ? 12u : 4u;      // bytes between horizontally adjacent pixels of one channel
+    const unsigned base = (unsigned)(yl * Wp + xl) * px, oob = 0x7ffffff0u;
+    const bool inside = x0 + QTILE_W <= W && y0 + TH <= H;     // every pixel of the tile lies inside the image
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned ro = base + (unsigned)(i * Wp) * px;
+      const float v[4] = {(float)acc[2 * i].x, (float)acc[2 * i].y, (float)acc[2 * i + 1].x, (float)acc[2 * i + 1].y};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = xl + 32 * q, row = yl + i;
+        // inside the image: the normalised pixel; between the image and the batch's padded extent: the padding's zero; beyond: no store
+        const bool in_img = inside || (row < H && col < W);
+        const float f = in_img ? (v[q] - m) / sd : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, f), out_rsrc, (in_img || (row < Hp && col < Wp)) ? ro + 32u * q * px : oob, 0, 0);
+      }
+    }
+  } else {
     // STEP: the plane offset ch * H * W * 2 is formed again here (from an opaque copy of ch) instead of staying alive from the
     // input descriptor's across the segment loop: two scalar registers the step kernel does not have (it spilled them).
     int chs = ch;
@@ -1084,6 +1120,31 @@ __global__ __launch_bounds__(256, 8) void blur_step_f16_kernel(BlurBatch batch, 
   __builtin_amdgcn_endpgm();
 }
 
+// The blur with the fused fp32 normalising store (dib_sparse_blur_normalized): blur_quad_f16_kernel's body, NORM store phase.
+template <int ACC, int KC>
+__global__ __launch_bounds__(256, 8) void blur_quad_f16_norm_kernel(BlurBatch batch, NormArgs na) {
+  constexpr int K = KC;
+  extern __shared__ unsigned nlds[];
+  const ImageDesc d = batch.img[blockIdx.y];
+  asm volatile("" ::"s"(d.in), "s"(d.out), "s"(d.C), "s"(d.H), "s"(d.W), "s"(d.table), "s"(d.tiles_x), "s"(d.tiles_y),
+               "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab));
+  const int per_ch = d.tiles_x * d.tiles_y;
+  int local;
+  if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
+  int ch;
+  if (na.nhwc) {   // channel fastest: the three workgroups that complete a pixel's 12 bytes are dispatched back to back on one XCD
+    const int t = magic_div(local, 0x55555556u);      // local / 3 (exact for local < 2^31)
+    ch = local - 3 * t;
+    local = t;
+  } else {
+    ch = magic_div(local, d.inv_per_ch);
+    local -= ch * per_ch;
+  }
+  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
+  blur_quad_tile_f16<ACC, false, false, NoWait, true>(d, d.tab, K, ch, tx, ty, lds_addr(nlds), __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), 0, 0,
+                                                      uint4{0, 0, 0, 0}, NoWait(), &na, (int)blockIdx.y);
+}
+
 // DIB_ACC_FP32 on the default tiles: the same kernel with sixteen fp32 accumulators per lane instead of eight packed ones (the
 // window fill goes in two parts to stay inside 64 registers: see the tile function).  Half the vector-ALU work of the bit-exact
 // mode per pixel and tap.
@@ -1248,6 +1309,10 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 256>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_norm_kernel<DIB_ACC_BITEXACT, 128>), QLDS_BYTES));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_norm_kernel<DIB_ACC_FMA16, 128>), QLDS_BYTES));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_norm_kernel<DIB_ACC_BITEXACT, 256>), QLDS_BYTES));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_norm_kernel<DIB_ACC_FMA16, 256>), QLDS_BYTES));
     DIB_HIP_CHECK(opt_in((blur_quad_f32acc_kernel<128>), QLDS_BYTES));
     DIB_HIP_CHECK(opt_in((blur_quad_f32acc_kernel<256>), QLDS_BYTES));
     DIB_HIP_CHECK(opt_in((blur_step_f16_kernel<DIB_ACC_BITEXACT>), QLDS_BYTES + STEP_LDS_EXTRA));
@@ -1459,6 +1524,56 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     }
     DIB_HIP_CHECK(hipGetLastError());
   }
+  return DIB_OK;
+}
+
+extern "C" int dib_sparse_blur_normalized(const void *const *in_dev, const int *H, const int *W, const int *table_index, const int *slot, int B,
+                                          void *tables_dev, int num_tables, int K, int acc_mode, const float *mean, const float *std,
+                                          float *out_dev, int Hp, int Wp, int channels_last, void *stream) {
+  if (B <= 0 || !in_dev || !H || !W || !table_index || !tables_dev || !mean || !std || !out_dev) {
+    set_error("dib_sparse_blur_normalized: null pointer or empty batch");
+    return DIB_EINVAL;
+  }
+  if (K != 128 && K != 256) { set_error("dib_sparse_blur_normalized: K must be 128 or 256, got %d", K); return DIB_EINVAL; }
+  if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FMA16) { set_error("dib_sparse_blur_normalized: DIB_ACC_BITEXACT or DIB_ACC_FMA16"); return DIB_EINVAL; }
+  if (Hp <= 0 || Wp <= 0 || (long long)Hp * Wp * 12 >= 0x7ffffff0ll) { set_error("dib_sparse_blur_normalized: bad padded size %d x %d", Hp, Wp); return DIB_EINVAL; }
+  if (B > MAX_BATCH || g_shape != 0) return 1;
+  std::vector<int> C((size_t)B, 3);
+  std::vector<void *> outs((size_t)B);
+  for (int i = 0; i < B; ++i) {
+    const int sl = slot ? slot[i] : i;
+    if (sl < 0 || sl >= B) { set_error("dib_sparse_blur_normalized: slot[%d] = %d out of range", i, sl); return DIB_EINVAL; }
+    outs[i] = out_dev + (size_t)sl * 3 * Hp * Wp;
+    if (table_index[i] < 0) return 1;                                         // an image that is not blurred: the unfused path
+    if (H[i] > Hp || W[i] > Wp) { set_error("dib_sparse_blur_normalized: image %d (%d x %d) exceeds the batch (%d x %d)", i, H[i], W[i], Hp, Wp); return DIB_EINVAL; }
+    // the padding is written by the tiles of the image: they have to cover the batch's extent
+    if ((H[i] + TH - 1) / TH * TH < Hp || (W[i] + QTILE_W - 1) / QTILE_W * QTILE_W < Wp) return 1;
+  }
+  if (int rc = check_images(in_dev, outs.data(), C.data(), H, W, table_index, B, K, num_tables)) return rc;
+  if (int rc = prepare_device()) return rc;
+  BlurBatch tiled;
+  NormArgs na;
+  na.Hp = Hp; na.Wp = Wp; na.nhwc = channels_last ? 1 : 0;
+  tiled.n = 0;
+  int tiles = 0;
+  for (int i = 0; i < B; ++i) {
+    const ImageDesc d = quad_desc(in_dev[i], outs[i], 3, H[i], W[i], table_index[i], (const int *)tables_dev, K, tiles);
+    tiled.tile_begin[tiled.n] = tiles;
+    tiles += d.C * d.tiles_x * d.tiles_y;
+    for (int c = 0; c < 3; ++c) { na.mean[tiled.n][c] = mean[i * 3 + c]; na.std[tiled.n][c] = std[i * 3 + c]; }
+    na.mean[tiled.n][3] = 0.f; na.std[tiled.n][3] = 1.f;
+    tiled.img[tiled.n++] = d;
+  }
+  for (int k = tiled.n; k <= MAX_BATCH; ++k) tiled.tile_begin[k] = tiles;
+  tiled.total_tiles = tiles;
+  tiled.xcd_bands = 1;
+  const dim3 grid(quad_grid_x(tiled), tiled.n);
+  hipStream_t s = (hipStream_t)stream;
+  if (acc_mode == DIB_ACC_FMA16 && K == 128) hipLaunchKernelGGL((blur_quad_f16_norm_kernel<DIB_ACC_FMA16, 128>), grid, dim3(256), QLDS_BYTES, s, tiled, na);
+  else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_quad_f16_norm_kernel<DIB_ACC_FMA16, 256>), grid, dim3(256), QLDS_BYTES, s, tiled, na);
+  else if (K == 128) hipLaunchKernelGGL((blur_quad_f16_norm_kernel<DIB_ACC_BITEXACT, 128>), grid, dim3(256), QLDS_BYTES, s, tiled, na);
+  else hipLaunchKernelGGL((blur_quad_f16_norm_kernel<DIB_ACC_BITEXACT, 256>), grid, dim3(256), QLDS_BYTES, s, tiled, na);
+  DIB_HIP_CHECK(hipGetLastError());
   return DIB_OK;
 }
 

@@ -184,6 +184,37 @@ def _estimate(blur_estimator, x, graphed):
     return cache(x).clone()
 
 
+# Opt-in (DIB_FUSE_BLUR_EPILOGUE=1, or set the flag): the training loop leaves the blur to the model's input transform, which
+# runs it TOGETHER with its float conversion + normalisation + zero-padded batch as one launch (blur_ops.sparse_blur_normalized)
+# when no image of the batch needs a resize -- the blurred fp16 batch then never exists (reference
+# engine.py:101, :107-110 + models/net_transforms.py:112-121, :238-247).  Bit-identical to the default path, which stays the
+# default: the reference blurs COCO at native size and resizes afterwards, where this does not apply and changes nothing.
+FUSE_BLUR_EPILOGUE = os.environ.get("DIB_FUSE_BLUR_EPILOGUE") == "1"
+
+
+def _postpone_blur(model, images_GPU, blur_dicts, psfs_GPU, tables, acc_mode=0):
+    """Hands the batch's blur to the model's input transform (`pending_blur`, consumed by its next forward) instead of launching
+    it.  False when that path is not available (no fused transform, tables that do not belong to the batch)."""
+    tf = getattr(getattr(model, "module", model), "transform", None)
+    if tf is None or not getattr(tf, "fused", False) or tables is None:
+        return False
+    idx = [i for i, bd in enumerate(blur_dicts) if bd["blurring"]]
+    if not idx or tables.count != len(idx) or tables.K != psfs_GPU[idx[0]].shape[0]:
+        return False
+    if any(psfs_GPU[i].dtype != images_GPU[i].dtype for i in idx):      # blur_image_list would convert those PSFs first
+        return False
+    index = [-1] * len(images_GPU)
+    for k, i in enumerate(idx):
+        index[i] = k
+    order = None
+    try:
+        order = sorted(range(len(images_GPU)), key=lambda i: -int(blur_dicts[i]["psf_taps"]) if blur_dicts[i]["blurring"] else 1)
+    except KeyError:
+        pass
+    tf.pending_blur = (index, tables, acc_mode, order)
+    return True
+
+
 def _tables_128(tables):
     """expand_targets refuses PSFs that are not 128 wide with the reference's own exception (utils.py:369-370): let it
     see the PSFs, not tables of another canvas."""
@@ -226,16 +257,24 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
     for images_CPU, targets, blur_dicts in metric_logger.log_every(data_loader, print_freq, header):
         images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables = _to_device(
             images_CPU, targets, blur_dicts, device, blur_train, want_tables=gpu_blur or expand_target_boxes)
+        postponed = False
         if gpu_blur and blur_train:
-            blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU=psfs_GPU, add_noise=add_noise,
-                                           noise_level=noise_level, add_block=add_block,
-                                           add_jpeg_artifact=add_jpeg_artifact, jpeg_compressor=jpeg_compressor, tables=tables)
+            if FUSE_BLUR_EPILOGUE and not (add_noise or add_block or add_jpeg_artifact):
+                postponed = _postpone_blur(model, images_GPU, blur_dicts, psfs_GPU, tables)
+            if not postponed:
+                blur_functions.blur_image_list(images_GPU, blur_dicts, psfs_GPU=psfs_GPU, add_noise=add_noise,
+                                               noise_level=noise_level, add_block=add_block,
+                                               add_jpeg_artifact=add_jpeg_artifact, jpeg_compressor=jpeg_compressor, tables=tables)
         if expand_target_boxes and blur_train:
             targets_GPU = utils.expand_targets(targets_GPU, blur_dicts, psfs_GPU, images_GPU, tables=_tables_128(tables))
         images_GPU = _to_float(images_GPU, model, device)
         norm_means, norm_stds = utils.get_norm_params(blur_dicts, use_custom_image_norm)
 
-        loss_dict = model(images_GPU, targets_GPU, thetas=thetas, lambda1s=l1, lambda2s=l2, newMeans=norm_means, newSTDs=norm_stds)
+        try:
+            loss_dict = model(images_GPU, targets_GPU, thetas=thetas, lambda1s=l1, lambda2s=l2, newMeans=norm_means, newSTDs=norm_stds)
+        finally:
+            if postponed:      # a forward pass that raised in front of the transform must not leave the blur behind for the next batch
+                getattr(model, "module", model).transform.__dict__.pop("pending_blur", None)
         losses = sum(loss for loss in loss_dict.values())
 
         loss_dict_reduced = utils.reduce_dict(loss_dict)                 # logging only

@@ -113,10 +113,27 @@ class GeneralizedRCNNTransform(nn.Module):
             scale = self.max_size / hi
         return scale
 
-    def _forward_fused(self, images, targets, newMeans, newSTDs):
+    def _qualifies_for_fused(self, images):
+        if not (self.fused and self.normalize_images and not self.crop_images and images):
+            return False
+        first = images[0]
+        return (first.is_cuda and first.dtype in (torch.float16, torch.float32)
+                and not any(i.dim() != 3 or i.shape[0] != 3 or i.dtype != first.dtype or not i.is_cuda for i in images))
+
+    @staticmethod
+    def _materialize(images, pending):
+        """The blur that `pending_blur` postponed, as its own launch: the images, blurred."""
+        from .. import blur_ops
+        index, tables, acc_mode = pending
+        return blur_ops.sparse_blur(list(images), list(index), tables, acc_mode)
+
+    def _forward_fused(self, images, targets, newMeans, newSTDs, pending=None):
         """None when the batch does not qualify (not on the GPU, mixed dtypes, crop mode, images that are not 3 x H x W);
         generator draws are consumed exactly as the unfused path would.  Images that need the resize of :151-175 (every
-        native-size COCO image) are resized by the same launch (dib_normalize_resize_pad)."""
+        native-size COCO image) are resized by the same launch (dib_normalize_resize_pad).
+        `pending` = (table_index, tables, acc_mode): the images are still UNBLURRED (engine.py, opt-in `FUSE_BLUR_EPILOGUE`); when
+        no image needs a resize the blur and this epilogue are ONE launch (blur_ops.sparse_blur_normalized: the blurred fp16
+        batch never exists), otherwise the blur is launched here first and everything goes on as usual."""
         if not (self.fused and self.normalize_images and not self.crop_images and images):
             return None
         first = images[0]
@@ -139,7 +156,16 @@ class GeneralizedRCNNTransform(nn.Module):
             return None                                         # degenerate sliver: let interpolate raise what it raises
         Hp = int(math.ceil(max(h for h, _ in out_hw) / 32.0) * 32)
         Wp = int(math.ceil(max(w for _, w in out_hw) / 32.0) * 32)
-        batch = blur_ops.normalize_pad(images, means, stds, Hp, Wp, getattr(self, "channels_last", False), out_sizes=out_hw)
+        batch = None
+        if pending is not None:
+            if out_hw == hw and first.dtype == torch.float16:
+                batch = blur_ops.sparse_blur_normalized(images, pending[0], pending[1], means, stds, Hp, Wp,
+                                                        getattr(self, "channels_last", False), pending[2], order=pending[3] if len(pending) > 3 else None)
+                self.last_epilogue = "fused into the blur" if batch is not None else "own launch"
+            if batch is None:
+                images = self._materialize(images, pending[:3])
+        if batch is None:
+            batch = blur_ops.normalize_pad(images, means, stds, Hp, Wp, getattr(self, "channels_last", False), out_sizes=out_hw)
         if targets is not None:
             for t, src, dst in zip(targets, hw, out_hw):
                 t["boxes"] = resize_boxes(t["boxes"], src, dst)
@@ -152,7 +178,11 @@ class GeneralizedRCNNTransform(nn.Module):
         for image in images:
             if image.dim() != 3:
                 raise ValueError("images is expected to be a list of 3d tensors of shape [C, H, W], got {}".format(image.shape))
-        fused = self._forward_fused(images, targets, newMeans, newSTDs)
+        pending = self.__dict__.pop("pending_blur", None)      # set by engine.py for ONE call: the images are still unblurred
+        if pending is not None and not self._qualifies_for_fused(images):
+            images = self._materialize(images, pending[:3])
+            pending = None
+        fused = self._forward_fused(images, targets, newMeans, newSTDs, pending)
         if fused is not None:
             return fused
         # Half images only arrive from engine.py when the fused path was expected to take them: convert as the

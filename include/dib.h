@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 5 /* 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad, dib_fold_bn_multi, dib_scale_rows_multi, dib_box_match / _encode_matched / _decode / _pool / _labels, dib_topk_levels, dib_det_candidates, dib_bias_act_transpose, the large LDS window; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 6 /* 6: + dib_sparse_blur_normalized (the blur with the input transform's float + normalise + zero-padded batch as its store phase); dib_blur_step runs compaction + blur as ONE launch where the shapes allow it (same results, same signature); 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad, dib_fold_bn_multi, dib_scale_rows_multi, dib_box_match / _encode_matched / _decode / _pool / _labels, dib_topk_levels, dib_det_candidates, dib_bias_act_transpose, the large LDS window; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -158,6 +158,20 @@ int dib_normalize_pad(const void *const *in_dev, int dtype, const int *H, const 
 int dib_normalize_resize_pad(const void *const *in_dev, int dtype, const int *H, const int *W, const int *Ho, const int *Wo, int B,
                              const float *mean, const float *std, float *out_dev, int Hp, int Wp, int channels_last,
                              void *stream);
+
+/* The blur WITH that epilogue as its store phase: dib_sparse_blur + dib_normalize_pad in one launch, for batches whose images
+ * need no resize (the model's internal scale factor is 1: BASELINE's synthetic 800 x 1333; the reference blurs, engine.py:101,
+ * converts to float, :107-110, and normalises + pads inside the model, net_transforms.py:112-121, :238-247 -- the blurred fp16
+ * image never has to exist).  in_dev: B device pointers to 3 x H[i] x W[i] fp16 images, table_index[i] >= 0 the table of
+ * tables_dev image i uses; slot (may be NULL = identity): the batch position image i goes to (the caller may hand the images over
+ * heaviest PSF first); mean / std: host [B][3] in the order of in_dev; out_dev: [B][3][Hp][Wp] fp32 planar or channels-last as
+ * dib_normalize_pad, padding pixels are written as 0 by the launch.  acc_mode: DIB_ACC_BITEXACT or DIB_ACC_FMA16.
+ * Returns DIB_OK, a negative error, or 1 = "not served, nothing launched" (an image that is not blurred, more than 32 images, a
+ * padded extent the image's own tiles do not cover: Hp > ceil(H / 32) * 32 or Wp > ceil(W / 128) * 128): the caller then takes
+ * the two-launch path.  Bit-identical to dib_sparse_blur followed by dib_normalize_pad. */
+int dib_sparse_blur_normalized(const void *const *in_dev, const int *H, const int *W, const int *table_index, const int *slot, int B,
+                               void *tables_dev, int num_tables, int K, int acc_mode, const float *mean, const float *std,
+                               float *out_dev, int Hp, int Wp, int channels_last, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Box growth and clamping: utils.py:360-392 (`expand_targets`, one image) and utils.py:395-434

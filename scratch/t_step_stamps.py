@@ -26,7 +26,7 @@ for rep in range(5):
     t0 = min(comp[:, 0].min(), blur[blur[:, 0] > 0, 0].min())
     c = (comp - t0) * 0.01     # us
     b = blur[blur[:, 0] > 0]
-    res.append({"compact_us_rel_t0 (start, scans, staged, segments+sum, tables, -, drained, signalled)": np.round(c, 2).tolist(),
+    res.append({"compact_us_rel_t0 (start, scans, staged, segments+sum+divide [record out], tables, -, drained, signalled)": np.round(c, 2).tolist(),
                 "blur_row0_start_us": [round(float(x), 2) for x in np.percentile((b[:, 0] - t0) * 0.01, [0, 50, 100])],
                 "blur_row0_ready_us": [round(float(x), 2) for x in np.percentile((b[:, 1] - t0) * 0.01, [0, 50, 100])],
                 "blur_row0_end_us": [round(float(x), 2) for x in np.percentile((b[:, 2] - t0) * 0.01, [0, 50, 100])]})
