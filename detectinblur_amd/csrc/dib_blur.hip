@@ -705,6 +705,10 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   typedef unsigned lds_u2v __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) lds_u2v lds_u2;
 
+#ifdef DIB_TIMELINE
+  if (!L && !STEP && wave == 0 && fresh_lane() == 0)
+    *(__attribute__((address_space(3))) unsigned long long *)(size_t)(lds0 + QGeom<false>::BYTES + 32) = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int sg = 0; sg < (STEP ? (nsegs & 0xffffff) : nsegs); ++sg) {
     if (sg > 0) seg = segs[sg];
     const Window w = window_of(seg);
@@ -760,6 +764,10 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
 #pragma unroll
         for (int k = 0; k < NK; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
       }
+#ifdef DIB_TIMELINE
+      if (!L && !STEP && sg == 0 && part == 0 && wave == 0 && fresh_lane() == 0)
+        *(__attribute__((address_space(3))) unsigned long long *)(size_t)(lds0 + QGeom<false>::BYTES + 40) = __builtin_amdgcn_s_memrealtime();
+#endif
       if (part == 0 && sg > 0) __syncthreads();  // every wave is done reading the previous window
       // Elements 0 .. 31 + column extent are read by the taps; writing all 56 of a row costs the same (an LDS store is
       // priced per instruction), lanes 56-63 own no element.  The two 16-bit values of a word are merged by v_perm_b32
@@ -813,6 +821,10 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       }
     }
     __syncthreads();
+#ifdef DIB_TIMELINE
+    if (!L && !STEP && sg == 0 && wave == 0 && fresh_lane() == 0)
+      *(__attribute__((address_space(3))) unsigned long long *)(size_t)(lds0 + QGeom<false>::BYTES + 16) = __builtin_amdgcn_s_memrealtime();
+#endif
     if constexpr (STEP) { if (sg == 0 && (nsegs >> 30)) wait_tables(); }
     const int tl = fresh_lane();
     const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
@@ -828,6 +840,10 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = h2{(_Float16)acc32[2 * i], (_Float16)acc32[2 * i + 1]};
   }
+#ifdef DIB_TIMELINE
+  if (!L && !STEP && wave == 0 && fresh_lane() == 0)
+    *(__attribute__((address_space(3))) unsigned long long *)(size_t)(lds0 + QGeom<false>::BYTES + 24) = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- store: a store instruction writes 32 columns of row y (lanes 0-31) and of row y + 4 (lanes 32-63); lanes
   // outside the image get an out-of-range buffer offset and are dropped by the range check ----------------------------
   if constexpr (NORM) {
@@ -899,7 +915,8 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
 }
 
 #ifdef DIB_TIMELINE
-// scratch/timeline.py: per-workgroup residency (100 MHz wall clock) + where it ran; never defined in the product build.
+// scratch/timeline.py, scratch/timeline_native.py: per-workgroup residency (100 MHz wall clock), where it ran and when wave 0 passed
+// its phases (prologue done, first window's loads issued, first window ready, taps done); never defined in the product build.
 // The begin stamp and the record index wait in 16 extra bytes of LDS and the buffer pointer is a device global read (volatile) at the end, so
 // that no value stays live across the tile function: a few more live SGPRs push the allocation from 80 to 96 (+16 for the trap
 // handler's) and cost a wave per SIMD, and the measurement would not be of the shipped kernel.
@@ -911,24 +928,42 @@ constexpr int TL_WORD = QLDS_BYTES / 4;
 // KC: the PSF canvas (128 or 256) as a compile-time constant -- table offsets, pads and the padding mode fold, ~50 scalar
 // instructions of every workgroup's prologue.  An instruction on a workgroup's serial path costs launch time out of
 // proportion (8 waves per SIMD: ~10 cycles per instruction and wave, times 3.2 rounds of workgroups).
-template <int ACC, int KC>
-__global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch) {
+// FLAT (ragged batches, dib_common.h: FlatBands): a 1-D grid of exactly the working workgroups; the image comes from one more
+// scalar load (the XCD list's 16 entry offsets) in front of the descriptor's.
+template <int ACC, int KC, bool FLAT = false>
+__global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, FlatBands fb) {
   constexpr int K = KC;
   extern __shared__ unsigned nlds[];
+  int img_i = blockIdx.y, entry = blockIdx.x >> 3;
+  if constexpr (FLAT) {
+    typedef int i16v __attribute__((ext_vector_type(16)));
+    const i16v bb = *reinterpret_cast<const i16v *>(fb.begin[blockIdx.x & 7]);
+    if (entry >= bb[15]) return;
+    int start = bb[0];
+    img_i = 0;
+#pragma unroll
+    for (int k = 1; k < FLAT_MAX; ++k) {
+      const bool ge = entry >= bb[k];
+      img_i += ge ? 1 : 0;
+      start = ge ? bb[k] : start;
+    }
+    entry -= start;
+  }
 #ifdef DIB_TIMELINE
-  if (threadIdx.x == 0) {   // 16 more bytes of LDS
+  if (threadIdx.x == 0) {   // 48 more bytes of LDS
     *(unsigned long long *)(nlds + TL_WORD) = __builtin_amdgcn_s_memrealtime();
-    nlds[TL_WORD + 2] = blockIdx.y * 1024 + blockIdx.x;   // x extent of the BASELINE launch: 832
+    nlds[TL_WORD + 2] = FLAT ? blockIdx.x : blockIdx.y * 1024 + blockIdx.x;   // x extent of the BASELINE launch: 832
+    nlds[TL_WORD + 3] = img_i;
   }
 #endif
   // Prologue = two scalar round trips.  First: the whole descriptor, K and the table base, requested together (left to
   // hipcc the fields are fetched one use at a time, a wait in front of each: six dependent round trips per workgroup).
-  const ImageDesc d = batch.img[blockIdx.y];
+  const ImageDesc d = batch.img[img_i];
   asm volatile("" ::"s"(d.in), "s"(d.out), "s"(d.C), "s"(d.H), "s"(d.W), "s"(d.table), "s"(d.tiles_x), "s"(d.tiles_y),
                "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab));
   const int per_ch = d.tiles_x * d.tiles_y;
   int local;
-  if (!band_entry(d.C * per_ch, blockIdx.x & 7, blockIdx.x >> 3, local)) return;
+  if (!band_entry(d.C * per_ch, blockIdx.x & 7, entry, local)) return;
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
   const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
@@ -938,10 +973,13 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch) 
     unsigned long long *tl = DIB_TL_SLOT;
     if (tl) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      unsigned long long *o = tl + 4 * (size_t)*(volatile unsigned *)(nlds + TL_WORD + 2);
+      unsigned long long *o = tl + 8 * (size_t)*(volatile unsigned *)(nlds + TL_WORD + 2);
       o[0] = *(volatile unsigned long long *)(nlds + TL_WORD);
       o[1] = __builtin_amdgcn_s_memrealtime();
-      o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      o[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | (unsigned long long)*(volatile unsigned *)(nlds + TL_WORD + 3) << 32;   // XCC id | image << 32
+      o[4] = *(volatile unsigned long long *)(nlds + TL_WORD + 4); o[5] = *(volatile unsigned long long *)(nlds + TL_WORD + 6);   // first window ready, taps done
+      o[6] = *(volatile unsigned long long *)(nlds + TL_WORD + 8); o[7] = *(volatile unsigned long long *)(nlds + TL_WORD + 10);  // prologue done, first window's loads issued
     }
   }
 #endif
@@ -1267,7 +1305,7 @@ extern "C" void dib_debug_set_stamp_buffer(void *dev_ptr) {
 #endif
 }
 #ifdef DIB_TIMELINE
-#define TL_EXTRA 16
+#define TL_EXTRA 48
 #else
 #define TL_EXTRA 0
 #endif
@@ -1283,6 +1321,10 @@ static int shape_from_env() {   // DIB_BLUR_SHAPE=0|1 runs a whole test suite on
 static int g_shape = shape_from_env();
 extern "C" void dib_debug_set_shape(int shape) { g_shape = shape == 1 ? 1 : 0; }
 extern "C" void dib_debug_set_tile_order(int xcd_bands) { g_xcd_bands = xcd_bands ? 1 : 0; }
+// Ragged batches on the default tiles: 1 = the 1-D grid of working workgroups (default), 0 = the 2-D grid (A/B runs, tests that
+// compare the two).
+static int g_flat_grid = !(getenv("DIB_FLAT_GRID") && getenv("DIB_FLAT_GRID")[0] == '0');
+extern "C" void dib_debug_set_flat_grid(int on) { g_flat_grid = on ? 1 : 0; }
 
 namespace {
 // Per-device launch state: the dynamic-LDS opt-in is a per-device function attribute.  Guarded by a mutex: entry
@@ -1307,6 +1349,8 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FMA16>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 128>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 128, true>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128, true>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_norm_kernel<DIB_ACC_BITEXACT, 128>), QLDS_BYTES));
@@ -1503,13 +1547,37 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
         }
         gx = ext > gx ? ext : gx;
       }
-      const dim3 grid(gx, tiled.n);
+      dim3 grid(gx, tiled.n);
+      // ragged batch on the default tiles: a 1-D grid of exactly the working workgroups (FlatBands, dib_common.h)
+      FlatBands fb = {};
+      bool flat = false;
+      if (quad && !large && K == 128 && g_flat_grid && tiled.n > 1 && tiled.n <= FLAT_MAX && acc_mode != DIB_ACC_FP32) {
+        for (int k = 1; k < tiled.n && !flat; ++k)
+          flat = tiled.tile_begin[k + 1] - tiled.tile_begin[k] != tiled.tile_begin[1] - tiled.tile_begin[0];
+        if (flat) {
+          int longest = 0;
+          for (int x = 0; x < 8; ++x) {
+            int at = 0;
+            for (int k = 0; k < 16; ++k) {
+              fb.begin[x][k] = k < tiled.n ? at : 0x7fffffff;
+              if (k < tiled.n) {
+                const int T = tiled.tile_begin[k + 1] - tiled.tile_begin[k];
+                at += (((x + 1) * T) >> 3) - ((x * T) >> 3);
+              }
+            }
+            fb.begin[x][15] = at;
+            longest = at > longest ? at : longest;
+          }
+          grid = dim3(8 * longest, 1);
+        }
+      }
 #define DIB_LAUNCH_QUAD(ACCM)                                                                                             \
   do {                                                                                                                   \
     if (large && K == 128) hipLaunchKernelGGL((blur_quad_large_f16_kernel<ACCM, 128>), grid, dim3(256), QGeom<true>::BYTES, s, tiled); \
     else if (large) hipLaunchKernelGGL((blur_quad_large_f16_kernel<ACCM, 256>), grid, dim3(256), QGeom<true>::BYTES, s, tiled);       \
-    else if (K == 128) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled); \
-    else hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 256>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled);          \
+    else if (flat) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128, true>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb); \
+    else if (K == 128) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb); \
+    else hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 256>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);          \
   } while (0)
       if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_QUAD(DIB_ACC_FMA16);
       else if (quad && acc_mode == DIB_ACC_FP32 && K == 128) hipLaunchKernelGGL((blur_quad_f32acc_kernel<128>), grid, dim3(256), QLDS_BYTES, s, tiled);

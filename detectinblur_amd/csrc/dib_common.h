@@ -130,6 +130,15 @@ struct StepSync {
   unsigned *rec;      // MAX_BATCH x STEP_REPLICAS x STEP_REC_WORDS words
 };
 
+// Flat grid of a RAGGED batch on the default tiles (dib_blur.hip: blur_quad_f16_kernel<.., FLAT = true>): the 2-D grid (band
+// entry x image) of a batch whose images differ in size is a third empty workgroups, and the dispatcher's round robin over the
+// CUs then leaves them 4-8 working ones each; a 1-D grid of exactly the working workgroups, heaviest image first, gives every
+// CU one workgroup of every 256 consecutive ones.  Workgroup b works for XCD list x = b & 7, entry t = b >> 3; list x is band
+// x of image 0, then band x of image 1, ...: begin[x][k] = entry at which image k starts (INT_MAX for k >= n), begin[x][15] =
+// the list's length.  One 64-byte scalar load per workgroup; at most FLAT_MAX images per launch.
+constexpr int FLAT_MAX = 15;
+struct FlatBands { int begin[8][16]; };
+
 struct BlurBatch {
   ImageDesc img[MAX_BATCH];
   int tile_begin[MAX_BATCH + 1];  // copy of img[i].tile_begin (+ total), contiguous for the image lookup

@@ -18,12 +18,12 @@ l = _lib.lib(); l.dib_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 for _ in range(50): blur_ops.sparse_blur(list(ordered), idx, tables)
 n = 16384
 for rep in range(3):
-    dbg = torch.zeros(n * 4, dtype=torch.int64, device="cuda")
+    dbg = torch.zeros(n * 8, dtype=torch.int64, device="cuda")
     l.dib_debug_set_stamp_buffer(dbg.data_ptr())
     for _ in range(2): blur_ops.sparse_blur(list(ordered), idx, tables)
     torch.cuda.synchronize()
     l.dib_debug_set_stamp_buffer(None)
-    d = dbg.cpu().numpy().reshape(n, 4)
+    d = dbg.cpu().numpy().reshape(n, 8)
     d = d[d[:, 1] != 0]
     t0 = d[:, 0].min()
     b, e = (d[:, 0] - t0) / 100.0, (d[:, 1] - t0) / 100.0          # microseconds

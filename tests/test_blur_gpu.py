@@ -419,6 +419,47 @@ def test_tile_shapes_and_orders_are_bit_identical():
         l.dib_debug_set_tile_order(1)
 
 
+@pytest.mark.parametrize("n_images", [2, 9, 15, 16])
+def test_ragged_batch_grids_are_bit_identical(n_images):
+    """A batch whose images differ in size runs on a 1-D grid of exactly its working workgroups (up to 15 images per launch:
+    FlatBands, csrc/dib_common.h), any other batch on the 2-D grid (band entry x image): same tiles, same outputs -- bit for bit
+    against the oracle, both modes, skipped entries and all, up to the flat grid's image limit and one past it."""
+    import ctypes
+    from detectinblur_amd import _lib, blur_ops
+    l = _lib.lib()
+    l.dib_debug_set_flat_grid.argtypes = [ctypes.c_int]
+    l.dib_debug_set_flat_grid.restype = None
+    rs = np.random.RandomState(100 + n_images)
+    shapes = [(3, 97, 301), (3, 333, 500), (1, 65, 65), (3, 480, 640), (2, 130, 257), (3, 70, 513), (3, 33, 140), (3, 200, 640),
+              (1, 300, 90), (2, 129, 384), (1, 96, 385), (3, 64 + 1, 700), (3, 427, 640), (3, 40, 40), (3, 257, 129), (3, 612, 612)]
+    imgs, psfs = [], []
+    for i in range(n_images):
+        imgs.append(rs.random_sample(shapes[i]).astype(np.float16))
+        sp = int(rs.choice([2, 5, 14, 30, 63]))
+        a = np.zeros((128, 128), np.float64)
+        n = 8 + 4 * sp
+        a[np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127), np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127)] = rs.random_sample(n) + 0.01
+        psfs.append(O.to_half_like_torch(a * 0.2))
+    index = list(range(n_images))
+    if n_images > 2:
+        index[1] = -1                          # one entry not blurred: it takes no part in the launch
+    want = [a.copy() for a in imgs]
+    O.blur_image_list(want, [{"blurring": t >= 0} for t in index], psfs)
+    tables = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=True)
+    try:
+        got = {}
+        for flat in (1, 0):
+            l.dib_debug_set_flat_grid(flat)
+            outs = blur_ops.sparse_blur([_dev(a) for a in imgs], index, tables)
+            for g, w in zip(outs, want):
+                assert np.array_equal(_bits(g.cpu().numpy().squeeze()), _bits(w.squeeze())), flat
+            got[flat] = blur_ops.sparse_blur([_dev(a) for a in imgs], index, tables, _lib.DIB_ACC_FMA16)
+        for a, b in zip(got[1], got[0]):
+            assert torch.equal(a, b)
+    finally:
+        l.dib_debug_set_flat_grid(1)
+
+
 def test_compaction_more_than_one_launch_chunk():
     """40 PSFs = two compaction launches (32 + 8): list and stacked entry points agree."""
     from detectinblur_amd import blur_ops
