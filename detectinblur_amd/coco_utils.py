@@ -132,11 +132,13 @@ def _coco_remove_images_without_annotations(dataset, cat_list=None):
 class SyntheticCocoDetection(torch.utils.data.Dataset):
     """Seeded random images + boxes from generator seed `seed + i`: the boxes first, then image i = `torch.rand(3, H, W)`;
     `boxes_per_image` boxes with x1, y1 uniform and w, h uniform in [32, 400] clipped to the image,
-    labels uniform in 1..num_classes-1."""
+    labels uniform in 1..num_classes-1.  `sizes`: a list of (H, W) that the items cycle through (image i has
+    sizes[i % len(sizes)]: the ragged sizes real COCO images come in) instead of the one `size`."""
 
     def __init__(self, num_images=64, size=(800, 1333), boxes_per_image=8, num_classes=91, transforms=None, seed=1337,
-                 as_tensor=True):
+                 as_tensor=True, sizes=None):
         self.num_images, self.size, self.boxes_per_image, self.num_classes = num_images, size, boxes_per_image, num_classes
+        self.sizes = [tuple(x) for x in sizes] if sizes else None
         self._transforms, self.seed, self.as_tensor = transforms, seed, as_tensor
         self.epoch_number = None
         self._epoch_number = 0
@@ -144,8 +146,11 @@ class SyntheticCocoDetection(torch.utils.data.Dataset):
     def __len__(self):
         return self.num_images
 
+    def size_of(self, idx):
+        return self.sizes[idx % len(self.sizes)] if self.sizes else self.size
+
     def _target(self, idx, g):
-        H, W = self.size
+        H, W = self.size_of(idx)
         n = self.boxes_per_image
         x1 = torch.rand(n, generator=g) * (W - 34)
         y1 = torch.rand(n, generator=g) * (H - 34)
@@ -157,7 +162,7 @@ class SyntheticCocoDetection(torch.utils.data.Dataset):
                 "area": (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]), "iscrowd": torch.zeros(n, dtype=torch.int64)}
 
     def __getitem__(self, idx):
-        H, W = self.size
+        H, W = self.size_of(idx)
         g = torch.Generator().manual_seed(self.seed + idx)
         target = self._target(idx, g)             # drawn first: `annotations` below then needs none of the image's draws
         img = torch.rand(3, H, W, generator=g)
@@ -181,7 +186,7 @@ def convert_to_coco_api(ds):
     categories, ann_id = set(), 1
     for img_idx in range(len(ds)):
         if hasattr(ds, "annotations"):
-            targets, height, width = ds.annotations(img_idx), ds.size[0], ds.size[1]
+            targets, (height, width) = ds.annotations(img_idx), ds.size_of(img_idx)
         else:
             img, targets, _ = ds[img_idx]
             height, width = (img.height, img.width) if hasattr(img, "height") else (img.shape[-2], img.shape[-1])

@@ -11,13 +11,14 @@
 // (key, index) pairs there.  A row of 201,600 scores (P2 at 800 x 1333) takes ~170 us, bound by the instruction rate of the ONE compute
 // unit that sweeps it four times (~20 instructions per element; a lower bound from per-thread maxima that spares most elements the
 // histogram atomics was tried and cost more than it saved: the sweeps are not atomics-bound) -- against ~350 us and 75 launches for
-// ATen's chain; splitting a row over workgroups is the next step if this ever matters.  Order: descending score, ascending index among equal scores (torch.topk leaves the order of ties
+// ATen's chain; callers split a long row into consecutive pieces (each a level of its own: up to 32 per launch) and merge the pieces' winners with a
+// second launch (models/detector_ops.py: topk_levels_split_hip) -- the 201,600-score row in 13 pieces: 66 us for both launches.  Order: descending score, ascending index among equal scores (torch.topk leaves the order of ties
 // unspecified; this one is deterministic), NaN above every number (as torch.topk ranks it).
 #include "dib_common.h"
 
 namespace dib {
 
-constexpr int TOPK_MAX_LEVELS = 16;
+constexpr int TOPK_MAX_LEVELS = 32;
 constexpr int TOPK_MAX_K = 2048;
 constexpr int TOPK_THREADS = 1024;
 

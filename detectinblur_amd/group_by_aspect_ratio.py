@@ -55,6 +55,8 @@ def compute_aspect_ratios(dataset, indices=None):
     if isinstance(dataset, torch.utils.data.Subset):
         return compute_aspect_ratios(dataset.dataset, [dataset.indices[i] for i in indices])
     if hasattr(dataset, "size") and not callable(dataset.size):            # SyntheticCocoDetection: one fixed (H, W)
+        if getattr(dataset, "sizes", None):
+            return [float(dataset.size_of(i)[1]) / float(dataset.size_of(i)[0]) for i in indices]
         return [float(dataset.size[1]) / float(dataset.size[0])] * len(indices)
     out = []
     for i in indices:                                                      # last resort: load every item

@@ -266,7 +266,10 @@ def det_candidates_hip(coder, class_logits, box_regression, rois, image_shape, s
     return scores, boxes, stats
 
 
-TOPK_SPLIT = 32768      # rows longer than this are selected in pieces (one workgroup sweeps a piece: ~0.8 us per 1000 elements)
+TOPK_SPLIT = 32768      # longest row dib_topk_levels is asked to select from in one piece (roi_heads: the detections' class-major score rows)
+TOPK_PIECE = 16384      # the RPN filter's levels longer than this are selected in pieces (one workgroup sweeps a piece: ~0.8 us per 1000
+                        # elements + ~25 us per piece whatever its length; 800 x 1333, b = 1: 166 us unsplit, 73 us at 32768, 66 us here)
+TOPK_MAX_LEVELS = 32    # csrc/dib_topk.hip
 
 
 def topk_levels_split_hip(values, counts, ks, K, boxes, clip_wh, min_size):
@@ -275,13 +278,13 @@ def topk_levels_split_hip(values, counts, ks, K, boxes, clip_wh, min_size):
     pieces' winners, laid out piece after piece, are still in ascending index order among equal scores -- the result is identical."""
     pieces, piece_ks, groups = [], [], []
     for c, k in zip(counts, ks):
-        n = max(1, -(-int(c) // TOPK_SPLIT))
+        n = max(1, -(-int(c) // TOPK_PIECE))
         base, rem = divmod(int(c), n)
         sizes = [base + (1 if i < rem else 0) for i in range(n)]
         pieces += sizes
         piece_ks += [min(int(k), s) for s in sizes]
         groups.append(n)
-    if len(pieces) == len(counts) or len(pieces) > 16:
+    if len(pieces) == len(counts) or len(pieces) > TOPK_MAX_LEVELS:
         s, _, b, v = topk_levels_hip(values, counts, ks, K, boxes, clip_wh, min_size)
         return s, b, v
     s1, _, b1, _ = topk_levels_hip(values, pieces, piece_ks, K, boxes, clip_wh, min_size)

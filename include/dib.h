@@ -267,7 +267,7 @@ int dib_bias_act_transpose(const float *in_dev, const float *bias_dev, float *ou
  * descending order -- equal scores in ascending index order, NaN first -- into out_scores_dev [N][L][K] (rows shorter than K end in
  * -inf), their level-relative indices into out_index_dev (optional).  With boxes_dev ([N][row_stride][4], same indexing): the
  * winners' boxes into out_boxes_dev [N][L][K][4], clipped to clip_wh_dev[n] = (width, height) when that is given, and
- * out_valid_dev [N][L][K] = score > -inf and both clipped sides >= min_size.  L <= 16.  (A long row is bound by the one compute unit
+ * out_valid_dev [N][L][K] = score > -inf and both clipped sides >= min_size.  L <= 32.  (A long row is bound by the one compute unit
  * that sweeps it: callers split it into consecutive levels and merge the winners with a second call -- the order is the same.) */
 int dib_topk_levels(const float *values_dev, long long row_stride, int N, const int *level_offset, const int *level_k, int L, int K,
                     const float *boxes_dev, const float *clip_wh_dev, float min_size, float *out_scores_dev, long long *out_index_dev,

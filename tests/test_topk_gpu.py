@@ -116,7 +116,7 @@ def test_split_rows_give_the_same_winners():
         s, _, b, v = ops.topk_levels_hip(obj, counts, ks, K, props, sizes, 1e-3)
         s2, b2, v2 = ops.topk_levels_split_hip(obj, counts, ks, K, props, sizes, 1e-3)
         assert torch.equal(s, s2) and torch.equal(b, b2) and torch.equal(v, v2)
-    assert ops.TOPK_SPLIT < counts[0]
+    assert ops.TOPK_PIECE < counts[0] and -(-counts[0] // ops.TOPK_PIECE) + -(-counts[1] // ops.TOPK_PIECE) + 3 <= ops.TOPK_MAX_LEVELS
 
 
 def test_limits_are_refused():
@@ -125,6 +125,6 @@ def test_limits_are_refused():
     with pytest.raises(_lib.DibError):
         ops.topk_levels_hip(v, [100], [10], 4096)
     with pytest.raises(_lib.DibError):
-        ops.topk_levels_hip(v, [5] * 17, [1] * 17, 4)
+        ops.topk_levels_hip(v, [3] * 33, [1] * 33, 4)
     with pytest.raises(_lib.DibError):
         ops.topk_levels_hip(v, [200], [10], 16)
