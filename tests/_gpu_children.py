@@ -145,7 +145,23 @@ def _evaluate_main_digest(argv):
             n += len(r["detections"][k]["boxes"])
         out[cell] = {"stats": [float(x) for x in r.coco_eval["bbox"].stats], "sha256": h.hexdigest(), "images": len(r["detections"]), "boxes": n}
     lines = [l for l in buf.getvalue().splitlines() if "Average Precision" in l or "Average Recall" in l]
-    return {"cells": out, "stat_lines": lines}
+    # what the kernel choice of this process rested on: the shipped find-db / TunableOp data (evaluate.main installs them) and
+    # whatever MIOpen appended to its private copy for shapes the data does not hold -- records of a find step run HERE, which a
+    # second process may rank differently
+    from detectinblur_amd import kernel_choices
+    rep = kernel_choices.report()
+    h = hashlib.sha256()
+    d = rep.get("miopen_user_db")
+    if d and os.path.isdir(d):
+        for f in sorted(os.listdir(d)):
+            if f.endswith(".lock") or f.endswith(".time") or not os.path.isfile(os.path.join(d, f)):
+                continue
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + b"\n".join(sorted(fh.read().splitlines())))
+    choice = {k: rep.get(k) for k in ("installed", "miopen_foreign_files", "miopen_db_growth_bytes", "tunableop_validators_match",
+                                      "tunableop_entries_loaded", "tunableop_shipped_entries")}
+    choice["miopen_db_sha256"] = h.hexdigest()
+    return {"cells": out, "stat_lines": lines, "kernel_choice": choice}
 
 
 def evaluate_main_digest(out_path, argv):
