@@ -480,18 +480,13 @@ static_assert(QPITCH == 448, "the asm below hard-codes the LDS row pitch");
 static_assert(LROWS % NW == 0, "every wave fills the same number of window rows");
 // The two window geometries of the quad shape (dib_common.h): L = false the standard one above, L = true the LARGE one
 // (21 x 64 segments, 52 rows x 96 elements = 39,936 B, 4 workgroups per CU) for launches that leave the chip's slots empty.
-// HH: the half-height form of the standard geometry -- a workgroup blurs 128 x 16 pixels (a lane: four columns of TWO rows), the
-// window is 28 rows; what the workgroups of a launch's last images run as, so that the launch drains in half-size steps.
-template <bool L, bool HH = false> struct QGeom {
-  static_assert(!(L && HH), "the large window has no half-height form");
+template <bool L> struct QGeom {
   static constexpr int PITCH_EL = L ? QUAD_PITCH_L : QUAD_PITCH;   // elements per LDS row
   static constexpr int PITCH = PITCH_EL * 8;                       // bytes per LDS row
-  static constexpr int TROWS = HH ? TH / 2 : TH;                   // tile rows
-  static constexpr int ROWS = TROWS + (L ? SEG_ROWS_L : SEG_ROWS); // LDS rows
+  static constexpr int ROWS = TH + (L ? SEG_ROWS_L : SEG_ROWS);    // LDS rows
   static constexpr int GQ = ROWS / NW;                             // rows a wave fills
   static constexpr int BYTES = ROWS * PITCH;
 };
-static_assert(QGeom<false, true>::ROWS % NW == 0, "every wave fills the same number of window rows");
 static_assert(QGeom<false>::PITCH == QPITCH && QGeom<false>::ROWS == LROWS && QGeom<false>::BYTES == QLDS_BYTES, "standard geometry");
 static_assert(QGeom<true>::PITCH == 768 && QGeom<true>::ROWS % NW == 0 && QGeom<true>::BYTES == 39936, "the asm below hard-codes the large window's row pitch");
 
@@ -582,52 +577,6 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
 }
 
-// Half-height tiles (QGeom<false, true>): a lane owns four columns of TWO rows -- 2 x ds_read_b64, 4 multiplies + 4 adds per tap; the
-// same scalar side and look-ahead as tap_loop_quad.  Operands: %0-%3 accumulators, %4 byte offset of the next ltap pair, %5 taps
-// left, %6 ltaps, %7 lane base.
-#define DIBH_MADD_X(W) DIBQ_MUL(32, W) DIBQ_MUL(33, W) DIBQ_MUL(34, W) DIBQ_MUL(35, W) DIBQ_ADD(32, 0) DIBQ_ADD(33, 1) DIBQ_ADD(34, 2) DIBQ_ADD(35, 3)
-#define DIBH_MADD_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(41, W) DIBQ_MUL(42, W) DIBQ_MUL(43, W) DIBQ_ADD(40, 0) DIBQ_ADD(41, 1) DIBQ_ADD(42, 2) DIBQ_ADD(43, 3)
-#define DIBH_FMADD_X(W) DIBQ_FMA(32, 0, W) DIBQ_FMA(33, 1, W) DIBQ_FMA(34, 2, W) DIBQ_FMA(35, 3, W)
-#define DIBH_FMADD_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(41, 1, W) DIBQ_FMA(42, 2, W) DIBQ_FMA(43, 3, W)
-#define DIBH_MADDH_X(W) DIBQ_MUL(32, W) DIBQ_MUL(34, W) DIBQ_ADD(32, 0) DIBQ_ADD(34, 2)
-#define DIBH_MADDH_Y(W) DIBQ_MUL(40, W) DIBQ_MUL(42, W) DIBQ_ADD(40, 0) DIBQ_ADD(42, 2)
-#define DIBH_FMADDH_X(W) DIBQ_FMA(32, 0, W) DIBQ_FMA(34, 2, W)
-#define DIBH_FMADDH_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(42, 2, W)
-#define DIBH_READ(base, OFF) "v_mad_u32_u16 v48, " OFF ", 1, %7\n\tds_read_b64 v[" #base ":" #base "+1], v48\n\tds_read_b64 v[" #base "+2:" #base "+3], v48 offset:448\n\t"
-#define DIBH_READH(base, OFF) "v_mad_u32_u16 v48, " OFF ", 1, %7\n\tds_read_b32 v[" #base "], v48\n\tds_read_b32 v[" #base "+2], v48 offset:448\n\t"
-#define DIBH_LOAD(PAIR) "s_load_dwordx2 " PAIR ", %6, %4\n\ts_add_u32 %4, %4, 8\n\t"
-#define DIBH_NEXT(LABEL) "s_sub_u32 %5, %5, 1\n\ts_cbranch_scc1 " LABEL "\n\t"
-template <bool FUSED, bool HALF>
-__device__ __forceinline__ void tap_loop_quad_hh(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
-  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
-  unsigned a[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
-#define DIB_RH_ASM(RD, ARITH_X, ARITH_Y) \
-  asm volatile( \
-      DIBH_LOAD("s[36:37]") DIBH_LOAD("s[38:39]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(32, "s36") \
-      "Ldibh_loop%=:\n\t" \
-      "s_waitcnt lgkmcnt(0)\n\t" DIBH_LOAD("s[40:41]") RD(40, "s37") ARITH_X("s36") DIBH_NEXT("Ldibh_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s38") ARITH_Y("s37") DIBH_NEXT("Ldibh_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" DIBH_LOAD("s[36:37]") RD(40, "s39") ARITH_X("s38") DIBH_NEXT("Ldibh_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s40") ARITH_Y("s39") DIBH_NEXT("Ldibh_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" DIBH_LOAD("s[38:39]") RD(40, "s41") ARITH_X("s40") DIBH_NEXT("Ldibh_done%=") \
-      "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s36") ARITH_Y("s41") \
-      "s_sub_u32 %5, %5, 1\n\ts_cbranch_scc0 Ldibh_loop%=\n\t" \
-      "Ldibh_done%=:\n\t" \
-      "s_waitcnt lgkmcnt(0)" \
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+s"(toff), "+s"(cnt) \
-      : "s"(ltaps), "v"(lane_addr) \
-      : "v32", "v33", "v34", "v35", "v40", "v41", "v42", "v43", "v48", "s36", "s37", "s38", "s39", "s40", "s41", "scc", "memory")
-  if constexpr (FUSED && HALF) { DIB_RH_ASM(DIBH_READH, DIBH_FMADDH_X, DIBH_FMADDH_Y); }
-  else if constexpr (FUSED) { DIB_RH_ASM(DIBH_READ, DIBH_FMADD_X, DIBH_FMADD_Y); }
-  else if constexpr (HALF) { DIB_RH_ASM(DIBH_READH, DIBH_MADDH_X, DIBH_MADDH_Y); }
-  else { DIB_RH_ASM(DIBH_READ, DIBH_MADD_X, DIBH_MADD_Y); }
-#undef DIB_RH_ASM
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
-}
-
 // DIB_ACC_FP32 on the quad shape: acc32 = fma(float(P), float(w), acc32) per pixel and tap, taps in the same order, ONE rounding
 // to fp16 at the store -- the product of two fp16 values is exact in fp32, so this equals the unfused form bit for bit (the
 // oracle restates it with numpy float32).  One v_fma_mix_f32 per pixel-tap (both fp16 factors converted inside the
@@ -702,17 +651,14 @@ struct NormArgs {
 // LDS byte address of a __shared__ array (the tile function takes the integer: with a generic pointer to LDS handed through the
 // call hipcc 7.2 emitted an illegal null test in some instantiations: "V_CMP_NE_U32_e32 0, $src_shared_base")
 __device__ __forceinline__ unsigned lds_addr(unsigned *shared) { return (unsigned)(size_t)(__attribute__((address_space(3))) char *)shared; }
-template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait, bool NORM = false, bool HH = false>
+template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait, bool NORM = false>
 __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
                                                    const unsigned lds0, const int wave, const int early = 0, const int nsegs0 = 0,
                                                    const uint4 seg0 = uint4{0, 0, 0, 0}, const Wait wait_tables = Wait(),
                                                    const NormArgs *na = nullptr, const int img = 0) {
 #pragma clang fp contract(off)
-  static_assert(!HH || (ACC != DIB_ACC_FP32 && !NORM), "half-height tiles: bit-exact and FMA16, fp16 store");
-  constexpr int GQ = QGeom<L, HH>::GQ;        // LDS rows a wave fills (11; large window: 15; half-height tiles: 7)
-  constexpr int QPITCH = QGeom<L, HH>::PITCH, QUAD_PITCH = QGeom<L, HH>::PITCH_EL, LROWS = QGeom<L, HH>::ROWS;   // shadow the standard geometry's constants
-  constexpr int TH = QGeom<L, HH>::TROWS;     // tile rows (32; half-height: 16 -- `ty` then counts 16-row steps)
-  constexpr int WR = TH / NW, LR = WR / 2;    // rows per wave (8 | 4) and per lane (4 | 2)
+  constexpr int GQ = QGeom<L>::GQ;            // LDS rows a wave fills (11; large window: 15)
+  constexpr int QPITCH = QGeom<L>::PITCH, QUAD_PITCH = QGeom<L>::PITCH_EL, LROWS = QGeom<L>::ROWS;   // shadow the standard geometry's constants
   const int H = d.H, W = d.W, w2 = W * 2;
   const int mode = pad_mode_for(K, H, W);
   const int pb = K / 2 - 1, pa = K / 2;
@@ -881,11 +827,8 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
 #endif
     if constexpr (STEP) { if (sg == 0 && (nsegs >> 30)) wait_tables(); }
     const int tl = fresh_lane();
-    const unsigned lane_addr = lds0 + (unsigned)((wave * WR + (tl >> 5) * LR) * QPITCH + (tl & 31) * 8);
-    if constexpr (HH) {
-      if (W - x0f() <= 64) tap_loop_quad_hh<ACC == DIB_ACC_FMA16, true>(acc, ltaps, w.t0, w.n, lane_addr);
-      else tap_loop_quad_hh<ACC == DIB_ACC_FMA16, false>(acc, ltaps, w.t0, w.n, lane_addr);
-    } else if constexpr (ACC == DIB_ACC_FP32) {
+    const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
+    if constexpr (ACC == DIB_ACC_FP32) {
       if (W - x0f() <= 64) tap_loop_quad_fp32<true, L>(acc32, ltaps, w.t0, w.n, lane_addr);
       else tap_loop_quad_fp32<false, L>(acc32, ltaps, w.t0, w.n, lane_addr);
     } else {
@@ -936,7 +879,7 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     const __amdgpu_buffer_rsrc_t out_rsrc = plane_rsrc(d.out, chs, H, W);
     const int x0 = x0f(), y0 = y0f();
     const int sl = fresh_lane();
-    const int yl = y0 + wave * WR + (sl >> 5) * LR, xl = x0 + (sl & 31);
+    const int yl = y0 + wave * 8 + (sl >> 5) * 4, xl = x0 + (sl & 31);
     const unsigned base = (unsigned)(yl * w2 + xl * 2), oob = 0x7ffffff0u;
     if (x0 + QTILE_W <= W && y0 + TH <= H) {
       // tile inside the image (5 of 6 at 800 x 1333): one address register, the row in the scalar offset, the column
@@ -948,7 +891,7 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
                       H * W * 2, 0x00020000};
       int so = 0;
 #pragma unroll
-      for (int i = 0; i < LR; ++i) {
+      for (int i = 0; i < 4; ++i) {
         asm volatile("buffer_store_short %0, %2, %3, %4 offen\n\t"
                      "buffer_store_short_d16_hi %0, %2, %3, %4 offen offset:64\n\t"
                      "buffer_store_short %1, %2, %3, %4 offen offset:128\n\t"
@@ -959,7 +902,7 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       return;
     }
 #pragma unroll
-    for (int i = 0; i < LR; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const bool row_ok = yl + i < H;
       const unsigned a0 = __builtin_bit_cast(unsigned, acc[2 * i]), a1 = __builtin_bit_cast(unsigned, acc[2 * i + 1]);
       const unsigned ro = base + (unsigned)(i * w2);
@@ -1024,12 +967,6 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
   const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  if (d.half) {     // half-height tail (host: half_tail_images): the upper or the lower 16 rows of the tile
-    const int ty2 = 2 * ty + d.half - 1;
-    if (ty2 * (TH / 2) >= d.H) return;
-    blur_quad_tile_f16<ACC, false, false, NoWait, false, true>(d, d.tab, K, ch, tx, ty2, lds_addr(nlds), __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
-    return;
-  }
   blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, lds_addr(nlds), __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));
 #ifdef DIB_TIMELINE
   if (threadIdx.x == 0) {
@@ -1386,15 +1323,6 @@ extern "C" void dib_debug_set_shape(int shape) { g_shape = shape == 1 ? 1 : 0; }
 extern "C" void dib_debug_set_tile_order(int xcd_bands) { g_xcd_bands = xcd_bands ? 1 : 0; }
 // Ragged batches on the default tiles: 1 = the 1-D grid of working workgroups (default), 0 = the 2-D grid (A/B runs, tests that
 // compare the two).
-// Half-height tail: how many of a launch's LAST images run as 128 x 16 half-tiles (0 = none) once the launch holds at least
-// 3 x 2,048 tiles -- several rounds of the chip's 2,048 slots: the last round then drains in half-size steps.
-static long long g_half_tail_min_tiles = 3 * 2048;
-static int g_half_tail = getenv("DIB_HALF_TAIL") ? atoi(getenv("DIB_HALF_TAIL")) : 1;
-// (tests: any launch of two or more images with min_tiles = 0; min_tiles < 0 restores the default threshold)
-extern "C" void dib_debug_set_half_tail(int n, long long min_tiles) {
-  g_half_tail = n < 0 ? 0 : (n > 8 ? 8 : n);
-  g_half_tail_min_tiles = min_tiles < 0 ? 3 * 2048 : min_tiles;
-}
 static int g_flat_grid = !(getenv("DIB_FLAT_GRID") && getenv("DIB_FLAT_GRID")[0] == '0');
 extern "C" void dib_debug_set_flat_grid(int on) { g_flat_grid = on ? 1 : 0; }
 
@@ -1483,7 +1411,6 @@ ImageDesc quad_desc(const void *in, void *out, int C, int H, int W, int table, c
   d.inv_tiles_x = magic_inverse((unsigned)d.tiles_x);
   d.tab = tables + (size_t)table * table_words(K);
   d.tile_begin = tile_begin;
-  d.half = 0;
   return d;
 }
 
@@ -1580,20 +1507,7 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     const bool quad = g_shape == 0 && dtype == DIB_F16;
     tiled.n = generic.n = 0;
     int tiles = 0, gblocks = 0;
-    // images of this launch: the next active ones, as many as fit (a half-height image takes two descriptors)
-    const bool may_halve = quad && !large && acc_mode != DIB_ACC_FP32 && g_half_tail > 0;
-    int n_act = 0, chunk_end = i;
-    long long chunk_tiles = 0;
-    for (int j = i; j < B && n_act < MAX_BATCH - (may_halve ? g_half_tail : 0); ++j) {
-      chunk_end = j + 1;
-      if (table_index[j] < 0) continue;
-      ++n_act;
-      chunk_tiles += (long long)C[j] * ((W[j] + QTILE_W - 1) / QTILE_W) * ((H[j] + TH - 1) / TH);
-    }
-    // half-height tail: the launch's last images run as 128 x 16 half-tiles when the launch is several rounds of workgroups long
-    const int n_half = may_halve && chunk_tiles >= g_half_tail_min_tiles ? (g_half_tail < n_act ? g_half_tail : n_act - 1) : 0;
-    int seen = 0;
-    for (; i < chunk_end; ++i) {
+    for (; i < B && tiled.n < MAX_BATCH; ++i) {
       if (table_index[i] < 0) continue;
       ImageDesc d;
       d.in = in_dev[i]; d.out = out_dev[i]; d.C = C[i]; d.H = H[i]; d.W = W[i]; d.table = table_index[i];
@@ -1602,17 +1516,11 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       d.inv_per_ch = magic_inverse((unsigned)(d.tiles_x * d.tiles_y));
       d.inv_tiles_x = magic_inverse((unsigned)d.tiles_x);
       d.tab = (const int *)tables_dev + (size_t)table_index[i] * table_words(K);
-      const bool halve = seen >= n_act - n_half;
-      ++seen;
-      for (int h = halve ? 1 : 0; h <= (halve ? 2 : 0); ++h) {
-        d.half = h;
-        d.tile_begin = tiles;
-        tiled.tile_begin[tiled.n] = tiles;
-        tiles += d.C * d.tiles_x * d.tiles_y;
-        tiled.img[tiled.n++] = d;
-      }
+      d.tile_begin = tiles;
+      tiled.tile_begin[tiled.n] = tiles;
+      tiles += d.C * d.tiles_x * d.tiles_y;
+      tiled.img[tiled.n++] = d;
       long long n = (long long)C[i] * H[i] * W[i];
-      d.half = 0;
       d.tile_begin = gblocks;
       gblocks += (int)((n + 255) / 256);
       generic.img[generic.n++] = d;
@@ -1745,7 +1653,7 @@ extern "C" int dib_sparse_blur_generic(const void *in_dev, void *out_dev, int C,
   BlurBatch g;
   g.n = 1;
   ImageDesc d;
-  d.in = in_dev; d.out = out_dev; d.C = C; d.H = H; d.W = W; d.table = 0; d.tile_begin = 0; d.tiles_x = d.tiles_y = 0; d.inv_per_ch = d.inv_tiles_x = 0; d.tab = (const int *)table_dev; d.half = 0;
+  d.in = in_dev; d.out = out_dev; d.C = C; d.H = H; d.W = W; d.table = 0; d.tile_begin = 0; d.tiles_x = d.tiles_y = 0; d.inv_per_ch = d.inv_tiles_x = 0; d.tab = (const int *)table_dev;
   g.img[0] = d;
   int blocks = (int)(((long long)C * H * W + 255) / 256);
   g.total_tiles = blocks;

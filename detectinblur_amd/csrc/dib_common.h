@@ -100,9 +100,6 @@ struct ImageDesc {
   // (channel, tile row, tile column) with two multiplies instead of two ~25-instruction scalar divisions per wave
   unsigned inv_per_ch, inv_tiles_x;
   const int *tab;  // this image's tap table (tables + table * table_words(K)), formed on the host
-  // Default tiles only: 0 = every workgroup of this descriptor blurs a whole 128 x 32 tile; 1 / 2 = its upper / lower 16 rows
-  // (the image then appears TWICE in the launch, once per half: dib_blur.hip, "half-height tail").
-  int half;
 };
 
 // n / d for n * d < 2^32, inv = floor(2^32 / d) + 1 (exact: the error term n * (inv * d - 2^32) / (d * 2^32) stays below 1 / d)

@@ -460,46 +460,6 @@ def test_ragged_batch_grids_are_bit_identical(n_images):
         l.dib_debug_set_flat_grid(1)
 
 
-@pytest.mark.parametrize("n_half", [1, 2, 8])
-def test_half_height_tail_is_bit_identical(n_half):
-    """The last images of a long launch run as 128 x 16 half-tiles (two descriptors per image: upper and lower halves; a lane owns
-    two rows instead of four) so that the launch drains in half-size steps.  Forced here on small launches: uniform and ragged
-    batches (2-D and 1-D grid), odd heights (a lower half that lies below the image), zero-padded small images, every PSF class,
-    both modes -- bit for bit the oracle's and the whole-tile path's result."""
-    import ctypes
-    from detectinblur_amd import _lib, blur_ops
-    l = _lib.lib()
-    l.dib_debug_set_half_tail.argtypes = [ctypes.c_int, ctypes.c_longlong]
-    l.dib_debug_set_half_tail.restype = None
-    rs = np.random.RandomState(300 + n_half)
-    for shapes in ([(3, 97, 301)] * 4, [(3, 97, 301), (3, 333, 500), (1, 65, 65), (3, 48, 640), (2, 130, 257), (3, 17, 513), (3, 33, 140), (3, 40, 40),
-                                         (3, 256, 256)]):
-        imgs, psfs = [], []
-        for sh in shapes:
-            imgs.append(rs.random_sample(sh).astype(np.float16))
-            sp = int(rs.choice([2, 5, 14, 30, 63]))
-            a = np.zeros((128, 128), np.float64)
-            n = 8 + 4 * sp
-            a[np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127), np.clip(rs.randint(-sp, sp + 1, n) + 63, 0, 127)] = rs.random_sample(n) + 0.01
-            psfs.append(O.to_half_like_torch(a * 0.2))
-        index = list(range(len(imgs)))
-        want = [a.copy() for a in imgs]
-        O.blur_image_list(want, [{"blurring": True}] * len(imgs), psfs)
-        tables = blur_ops.compact_psfs(_dev(np.stack(psfs)), normalize=True)
-        try:
-            fma = {}
-            for half in (n_half, 0):
-                l.dib_debug_set_half_tail(half, 0)
-                outs = blur_ops.sparse_blur([_dev(a) for a in imgs], index, tables)
-                for g, w in zip(outs, want):
-                    assert np.array_equal(_bits(g.cpu().numpy().squeeze()), _bits(w.squeeze())), half
-                fma[half] = blur_ops.sparse_blur([_dev(a) for a in imgs], index, tables, _lib.DIB_ACC_FMA16)
-            for a, b in zip(fma[n_half], fma[0]):
-                assert torch.equal(a, b)
-        finally:
-            l.dib_debug_set_half_tail(1, -1)
-
-
 def test_compaction_more_than_one_launch_chunk():
     """40 PSFs = two compaction launches (32 + 8): list and stacked entry points agree."""
     from detectinblur_amd import blur_ops
