@@ -22,11 +22,11 @@ for sub in ("fetch_cold", "write_cold"):
 stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(stats)))
 step = [r for r in rows if "blur_step_f16_kernel<0>" in r["Name"]][0]
-blur = [r for r in rows if "blur_quad_f16_kernel<0, 128>" in r["Name"]][0]
+blur = [r for r in rows if "blur_quad_f16_kernel<0, 128, false>" in r["Name"]][0]
 trace = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
 durs = {"step": [], "blur": []}
 tr = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace))
-            if "blur_step_f16_kernel<0>" in r["Kernel_Name"] or "blur_quad_f16_kernel<0, 128>" in r["Kernel_Name"])
+            if "blur_step_f16_kernel<0>" in r["Kernel_Name"] or "blur_quad_f16_kernel<0, 128, false>" in r["Kernel_Name"])
 # maximal runs of back-to-back launches of ONE kernel: the roofline loops of bench.py are the longest runs of each
 def longest_run(name):
     best, cur = [], []
@@ -55,7 +55,7 @@ doc = {
     "per_launch_cold": {k: cold[k] for k in sorted(cold)},
     "kernel_avg_ns": float(step["AverageNs"]), "kernel_calls": int(step["Calls"]),
     "kernel_avg_ns_roofline_loop": sum(loop_step) / len(loop_step), "roofline_loop_calls": len(loop_step),
-    "blur_only": {"kernel": "dib::blur_quad_f16_kernel<0, 128>", "kernel_avg_ns": float(blur["AverageNs"]), "kernel_calls": int(blur["Calls"]),
+    "blur_only": {"kernel": "dib::blur_quad_f16_kernel<0, 128, false>", "kernel_avg_ns": float(blur["AverageNs"]), "kernel_calls": int(blur["Calls"]),
                   "kernel_avg_ns_roofline_loop": sum(loop_blur) / len(loop_blur), "roofline_loop_calls": len(loop_blur)},
     "unprofiled_same_box": {"kernel_ms": default["roofline"]["kernel_ms"], "blur_only_kernel_ms": default["roofline"]["blur_only"]["kernel_ms"],
                             "ms_per_step": default["ms_per_step"], "value": default["value"],
