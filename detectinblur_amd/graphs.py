@@ -62,7 +62,6 @@ class GraphCache(object):
             self.seen.pop(next(iter(self.seen)))
         if n < self.capture_after:
             return self.fn(x)
-        self.seen.pop(key, None)                                       # captured (or failed) from here on: `graphs` remembers it
         while len(self.graphs) >= self.limit:
             self.graphs.pop(next(iter(self.graphs)))        # least recently used
         if self.pool is None:
