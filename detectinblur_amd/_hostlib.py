@@ -28,6 +28,8 @@ _SIGNATURES = {
     "dib_psf_center": (ctypes.c_int, [_dp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "dib_rng_uniform": (ctypes.c_double, [ctypes.POINTER(MT19937)]),
     "dib_rng_gauss": (ctypes.c_double, [ctypes.POINTER(MT19937)]),
+    "dib_mask_or_polygon": (ctypes.c_int, [_dp, ctypes.c_long, ctypes.c_long, ctypes.c_long, _u8p]),
+    "dib_mask_or_runs": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint), ctypes.c_long, ctypes.c_long, ctypes.c_long, _u8p]),
     "dib_coco_match": (ctypes.c_int, [_dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_longlong), _dp, _dp, ctypes.c_int, _dp,
                                       ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_int)]),
 }

@@ -5,8 +5,9 @@ Two datasets, one layout:
     read with `json` + PIL only: neither torchvision.datasets.CocoDetection nor pycocotools is needed for the
     box path (reference coco_utils.py:231-271).  `ConvertCocoPolysToMask` turns the raw annotations into the
     target dict of reference coco_utils.py:51-104 (`boxes` xyxy float32 clipped to the image, `labels` int64,
-    `image_id`, `area`, `iscrowd`); segmentation masks need pycocotools' RLE decoder and are NOT produced
-    (Faster R-CNN never reads them).  Training drops images without a usable annotation (:106-147).
+    `masks` uint8 [N, h, w] rasterised from the polygons by native host code -- pycocotools' rleFrPoly restated, bit-identical
+    to the reference's own maskApi.c --, `keypoints` when present, `image_id`, `area`, `iscrowd`).  Training drops images
+    without a usable annotation (:106-147).
   * `SyntheticCocoDetection` -- COCO-shaped random images and boxes, the offline stand-in (`--synthetic`).
 `get_coco_api_from_dataset` (reference :218-226) hands `engine.evaluate` the ground truth as a `CocoGT`
 (the few fields of pycocotools' COCO object the evaluation reads: `dataset`, `imgToAnns`, `imgs`).
@@ -56,10 +57,77 @@ class CocoGT(object):
         return sorted(self.imgs)
 
 
+def _one_object_mask(segmentation, height, width):
+    """`coco_mask.decode(coco_mask.frPyObjects(segmentation, height, width))` reduced with `any` over the object's parts (reference
+    coco_utils.py:37-43), as one uint8 [height, width] array: the segmentation forms pycocotools' frPyObjects accepts
+    (cocoapi/PythonAPI/pycocotools/_mask.pyx:288-308) -- a list of polygons (more than four numbers each), a list of [x, y, w, h]
+    boxes (four numbers each: rasterised as their four corners), a list of uncompressed RLE dicts, or one polygon / box / RLE dict
+    -- rasterised by native host code (csrc/host/dib_host.c: dib_mask_or_polygon, the restatement of maskApi.c's rleFrPoly)."""
+    import ctypes
+    from . import _hostlib
+    lib = _hostlib.lib()
+    mask = np.zeros((height, width), dtype=np.uint8)
+    mp = mask.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))
+
+    def polygon(p):
+        xy = np.array(p, dtype=np.float64)
+        if lib.dib_mask_or_polygon(_hostlib.dptr(xy), int(len(p) / 2), height, width, mp) != 0:
+            raise ValueError("polygon of %d numbers on a %d x %d image cannot be rasterised" % (len(p), height, width))
+
+    def box(b):
+        xs, ys, xe, ye = float(b[0]), float(b[1]), float(b[0]) + float(b[2]), float(b[1]) + float(b[3])
+        polygon([xs, ys, xs, ye, xe, ye, xe, ys])                           # maskApi.c:148-156 (rleFrBbox)
+
+    def runs(r):
+        if tuple(r["size"]) != (height, width):
+            raise ValueError("RLE of size %s on a %d x %d image" % (r["size"], height, width))
+        cnts = np.array(r["counts"], dtype=np.uint32)
+        if lib.dib_mask_or_runs(cnts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)), len(cnts), height, width, mp) != 0:
+            raise ValueError("bad RLE")
+
+    def is_rle(o):
+        return type(o) == dict and "counts" in o and "size" in o
+
+    o = segmentation
+    if type(o) == list and len(o) == 0:
+        pass            # no outline (box-only annotations): an empty mask, where pycocotools raises IndexError
+    elif type(o) == list and len(o[0]) == 4:
+        for b in o:
+            box(b)
+    elif type(o) == list and len(o[0]) > 4:
+        for p in o:
+            polygon(p)
+    elif type(o) == list and is_rle(o[0]):
+        for r in o:
+            runs(r)
+    elif type(o) == list and len(o) == 4:
+        box(o)
+    elif type(o) == list and len(o) > 4:
+        polygon(o)
+    elif is_rle(o):
+        runs(o)
+    else:
+        raise Exception("input type is not supported.")
+    return mask
+
+
+def convert_coco_poly_to_mask(segmentations, height, width):
+    """reference coco_utils.py:34-49: one uint8 mask per object, [N, height, width] ([0, height, width] for no object)."""
+    masks = [torch.from_numpy(_one_object_mask(seg, height, width)) for seg in segmentations]
+    if masks:
+        return torch.stack(masks, dim=0)
+    return torch.zeros((0, height, width), dtype=torch.uint8)
+
+
 class ConvertCocoPolysToMask(object):
-    """reference coco_utils.py:51-104, box path: crowd annotations are dropped from the target, xywh -> xyxy,
-    clamped to the image, boxes without positive extent dropped; `area` / `iscrowd` keep one entry per
-    non-crowd annotation (NOT filtered by `keep`, as in the reference)."""
+    """reference coco_utils.py:51-104: crowd annotations are dropped from the target, xywh -> xyxy, clamped to the image, boxes
+    without positive extent dropped together with their labels, masks and keypoints; `area` / `iscrowd` keep one entry per
+    non-crowd annotation (NOT filtered by `keep`, as in the reference).  `masks` uint8 [N, h, w] from the objects'
+    `segmentation` (polygons / RLE), `keypoints` float32 [N, K, 3] when the annotations carry them.  `with_masks=False` skips the
+    masks (Faster R-CNN never reads them; the reference always builds them)."""
+
+    def __init__(self, with_masks=True):
+        self.with_masks = with_masks
 
     def __call__(self, image, target, blur_dict=None):
         blur_dict = {} if blur_dict is None else blur_dict
@@ -71,9 +139,21 @@ class ConvertCocoPolysToMask(object):
         boxes[:, 0::2].clamp_(min=0, max=w)
         boxes[:, 1::2].clamp_(min=0, max=h)
         classes = torch.tensor([obj["category_id"] for obj in anno], dtype=torch.int64)
+        masks = convert_coco_poly_to_mask([obj.get("segmentation", []) for obj in anno], h, w) if self.with_masks else None
+        keypoints = None
+        if anno and "keypoints" in anno[0]:
+            keypoints = torch.as_tensor([obj["keypoints"] for obj in anno], dtype=torch.float32)
+            if keypoints.shape[0]:
+                keypoints = keypoints.view(keypoints.shape[0], -1, 3)
         keep = (boxes[:, 3] > boxes[:, 1]) & (boxes[:, 2] > boxes[:, 0])
-        out = {"boxes": boxes[keep], "labels": classes[keep], "image_id": image_id,
-               "area": torch.tensor([obj["area"] for obj in anno]), "iscrowd": torch.tensor([obj["iscrowd"] for obj in anno])}
+        out = {"boxes": boxes[keep], "labels": classes[keep]}
+        if masks is not None:
+            out["masks"] = masks[keep]
+        out["image_id"] = image_id
+        if keypoints is not None:
+            out["keypoints"] = keypoints[keep]
+        out["area"] = torch.tensor([obj["area"] for obj in anno])
+        out["iscrowd"] = torch.tensor([obj["iscrowd"] for obj in anno])
         return image, out, blur_dict
 
 

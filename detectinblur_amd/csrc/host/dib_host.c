@@ -3,6 +3,7 @@
 #include <complex.h>
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "../../../include/dib_host.h"
 
@@ -404,5 +405,100 @@ int dib_coco_accumulate_cat(const double *scores, const int *lens, int nrec, con
     }
   }
   __builtin_free(idx); __builtin_free(tmp); __builtin_free(rc); __builtin_free(pr);
+  return 0;
+}
+
+/* ---- segmentation masks of ConvertCocoPolysToMask (reference coco_utils.py:34-49: frPyObjects + decode + any) -----------------
+ * A polygon is rasterised the way pycocotools does it (cocoapi/common/maskApi.c:162-218, rleFrPoly), restated:
+ *   1. vertices to a grid five times finer than the pixels, (int)(5 v + 0.5) per coordinate (C truncation, as there);
+ *   2. every edge walked along its longer axis, one grid point per step, the other coordinate (int)(start + slope * t + 0.5);
+ *      an edge that runs backwards along its longer axis is walked from its far end so that the points come out in order;
+ *   3. wherever the walk's x changes, the crossing of a pixel-column boundary is kept if it falls on a pixel centre's column
+ *      (x5 -> (x5 + 0.5) / 5 - 0.5 integral and inside [0, w - 1]), with the row clamped to [0, h] and rounded up;
+ *   4. the crossings, as column-major positions x * h + y, sorted: consecutive differences are the run lengths of a column-major
+ *      mask that starts with zeros (the image's end h * w closes the last run); zero-length runs merge their neighbours.
+ * The runs are decoded straight into the row-major byte mask [h][w], OR-ing (the reference takes `any` over an object's
+ * polygons).  Returns 0, -1 on bad arguments, -3 out of memory. */
+static int dib_cmp_u32(const void *a, const void *b) {
+  const unsigned x = *(const unsigned *)a, y = *(const unsigned *)b;
+  return x > y ? 1 : (x < y ? -1 : 0);
+}
+
+/* runs of a column-major mask (first run zeros) OR-ed into the row-major mask */
+static void dib_runs_or(const unsigned *runs, long n_runs, long h, long w, unsigned char *mask) {
+  const unsigned long long total = (unsigned long long)h * (unsigned long long)w;
+  unsigned long long at = 0;
+  int v = 0;
+  for (long r = 0; r < n_runs && at < total; ++r, v = !v) {
+    unsigned long long end = at + runs[r];
+    if (end > total) end = total;
+    if (v)
+      for (unsigned long long p = at; p < end; ++p) mask[(p % (unsigned long long)h) * (unsigned long long)w + p / (unsigned long long)h] = 1;
+    at = end;
+  }
+}
+
+int dib_mask_or_runs(const unsigned *runs, long n_runs, long h, long w, unsigned char *mask) {
+  if (!runs || n_runs < 0 || h <= 0 || w <= 0 || !mask) return -1;
+  dib_runs_or(runs, n_runs, h, w, mask);
+  return 0;
+}
+
+int dib_mask_or_polygon(const double *xy, long k, long h, long w, unsigned char *mask) {
+  if (!xy || k <= 0 || h <= 0 || w <= 0 || !mask || (unsigned long long)h * (unsigned long long)w >= 0xffffffffull) return -1;
+  const double scale = 5;
+  int *vx = (int *)__builtin_malloc(sizeof(int) * (size_t)(k + 1)), *vy = (int *)__builtin_malloc(sizeof(int) * (size_t)(k + 1));
+  if (!vx || !vy) { __builtin_free(vx); __builtin_free(vy); return -3; }
+  for (long j = 0; j < k; ++j) { vx[j] = (int)(scale * xy[2 * j] + .5); vy[j] = (int)(scale * xy[2 * j + 1] + .5); }
+  vx[k] = vx[0]; vy[k] = vy[0];
+  size_t n_pts = 0;
+  for (long j = 0; j < k; ++j) {
+    const int ax = __builtin_abs(vx[j] - vx[j + 1]), ay = __builtin_abs(vy[j] - vy[j + 1]);
+    n_pts += (size_t)(ax > ay ? ax : ay) + 1;
+  }
+  int *px = (int *)__builtin_malloc(sizeof(int) * (n_pts + 1)), *py = (int *)__builtin_malloc(sizeof(int) * (n_pts + 1));
+  unsigned *pos = (unsigned *)__builtin_malloc(sizeof(unsigned) * (n_pts + 2));
+  unsigned *runs = (unsigned *)__builtin_malloc(sizeof(unsigned) * (n_pts + 2));
+  if (!px || !py || !pos || !runs) { __builtin_free(vx); __builtin_free(vy); __builtin_free(px); __builtin_free(py); __builtin_free(pos); __builtin_free(runs); return -3; }
+  size_t m = 0;
+  for (long j = 0; j < k; ++j) {          /* step 2: the dense boundary */
+    int x0 = vx[j], x1 = vx[j + 1], y0 = vy[j], y1 = vy[j + 1];
+    const int dx = __builtin_abs(x1 - x0), dy = __builtin_abs(y0 - y1);
+    const int along_x = dx >= dy;
+    const int backwards = (along_x && x0 > x1) || (!along_x && y0 > y1);
+    if (backwards) { int t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
+    const double slope = along_x ? (double)(y1 - y0) / dx : (double)(x1 - x0) / dy;      /* dx == dy == 0: NaN, used with t = 0 only (as there) */
+    const int len = along_x ? dx : dy;
+    for (int d = 0; d <= len; ++d) {
+      const int t = backwards ? len - d : d;
+      if (along_x) { px[m] = t + x0; py[m] = (int)(y0 + slope * t + .5); }
+      else { py[m] = t + y0; px[m] = (int)(x0 + slope * t + .5); }
+      ++m;
+    }
+  }
+  size_t n_cross = 0;
+  for (size_t j = 1; j < m; ++j) {        /* step 3: crossings of pixel-column boundaries */
+    if (px[j] == px[j - 1]) continue;
+    double xd = (double)(px[j] < px[j - 1] ? px[j] : px[j] - 1);
+    xd = (xd + .5) / scale - .5;
+    if (__builtin_floor(xd) != xd || xd < 0 || xd > (double)(w - 1)) continue;
+    double yd = (double)(py[j] < py[j - 1] ? py[j] : py[j - 1]);
+    yd = (yd + .5) / scale - .5;
+    if (yd < 0) yd = 0; else if (yd > (double)h) yd = (double)h;
+    yd = __builtin_ceil(yd);
+    pos[n_cross++] = (unsigned)((int)xd * (int)h + (int)yd);
+  }
+  pos[n_cross++] = (unsigned)((unsigned long long)h * (unsigned long long)w);
+  qsort(pos, n_cross, sizeof(unsigned), dib_cmp_u32);
+  unsigned prev = 0;
+  for (size_t j = 0; j < n_cross; ++j) { const unsigned t = pos[j]; pos[j] -= prev; prev = t; }     /* step 4: differences */
+  size_t n_runs = 0, j = 0;
+  runs[n_runs++] = pos[j++];
+  while (j < n_cross) {
+    if (pos[j] > 0) runs[n_runs++] = pos[j++];
+    else { ++j; if (j < n_cross) runs[n_runs - 1] += pos[j++]; }          /* an empty run joins the runs on either side of it */
+  }
+  dib_runs_or(runs, (long)n_runs, h, w, mask);
+  __builtin_free(vx); __builtin_free(vy); __builtin_free(px); __builtin_free(py); __builtin_free(pos); __builtin_free(runs);
   return 0;
 }

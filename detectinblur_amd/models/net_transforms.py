@@ -73,8 +73,22 @@ class GeneralizedRCNNTransform(nn.Module):
                                   align_corners=False)[0]
         if target is None:
             return image, target
-        target["boxes"] = resize_boxes(target["boxes"], (h, w), image.shape[-2:])
+        self._resize_target(target, (h, w), tuple(image.shape[-2:]), scale)
         return image, target
+
+    @staticmethod
+    def _resize_target(target, src, dst, scale):
+        """What the resize does to a target (reference net_transforms.py:52-55, :165-172, :283-299): masks by nearest neighbour
+        with the image's scale factor, boxes and keypoints by the ratio of the sizes."""
+        if "masks" in target:
+            target["masks"] = F.interpolate(target["masks"][:, None].float(), scale_factor=scale)[:, 0].byte()
+        target["boxes"] = resize_boxes(target["boxes"], src, dst)
+        if "keypoints" in target:
+            rh, rw = (float(np.float32(n) / np.float32(o)) for n, o in zip(dst, src))
+            kp = target["keypoints"].clone()
+            kp[..., 0] *= rw
+            kp[..., 1] *= rh
+            target["keypoints"] = kp
 
     def batch_images(self, images, size_divisible=32):
         shapes = [list(img.shape) for img in images]
@@ -147,9 +161,10 @@ class GeneralizedRCNNTransform(nn.Module):
         means = newMeans if newMeans is not None else np.tile(np.asarray(self.image_mean, dtype=np.float64), (n, 1))
         stds = newSTDs if newSTDs is not None else np.tile(np.asarray(self.image_std, dtype=np.float64), (n, 1))
         hw = [(int(i.shape[-2]), int(i.shape[-1])) for i in images]
-        out_hw = []
+        out_hw, scales = [], []
         for (h, w), s in zip(hw, sizes):
             scale = self._scale(h, w, s)
+            scales.append(scale)
             # F.interpolate(..., scale_factor=scale, recompute_scale_factor=True): output size int(size * scale), per dimension
             out_hw.append((h, w) if scale == 1.0 else (int(h * scale), int(w * scale)))
         if any(oh <= 0 or ow <= 0 for oh, ow in out_hw):
@@ -167,8 +182,8 @@ class GeneralizedRCNNTransform(nn.Module):
         if batch is None:
             batch = blur_ops.normalize_pad(images, means, stds, Hp, Wp, getattr(self, "channels_last", False), out_sizes=out_hw)
         if targets is not None:
-            for t, src, dst in zip(targets, hw, out_hw):
-                t["boxes"] = resize_boxes(t["boxes"], src, dst)
+            for t, src, dst, scale in zip(targets, hw, out_hw, scales):
+                self._resize_target(t, src, dst, scale)
         return ImageList(batch, out_hw), targets
 
     def forward(self, images, targets=None, newMeans=None, newSTDs=None):

@@ -71,6 +71,13 @@ int dib_coco_accumulate_cat(const double *scores, const int *lens, int nrec, con
                             const int *n_gt, int A, int T, const int *max_dets, int M, const double *rec_thrs, int R,
                             double *precision_out, double *recall_out);
 
+/* Segmentation masks of ConvertCocoPolysToMask (reference coco_utils.py:34-49 = pycocotools frPyObjects + decode + any over an
+ * object's polygons; rasterisation as cocoapi/common/maskApi.c:162-218 rleFrPoly does it, decode as :43-47).  xy: k vertices
+ * (x0, y0, x1, y1, ...) in pixel units; the polygon's pixels are OR-ed into mask [h][w] (row-major bytes, 0 / 1).
+ * dib_mask_or_runs: an uncompressed RLE's run lengths (column-major, first run zeros).  Return 0, -1 bad arguments, -3 memory. */
+int dib_mask_or_polygon(const double *xy, long k, long h, long w, unsigned char *mask);
+int dib_mask_or_runs(const unsigned *runs, long n_runs, long h, long w, unsigned char *mask);
+
 #ifdef __cplusplus
 }
 #endif
