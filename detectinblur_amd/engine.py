@@ -254,6 +254,11 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
 
     iteration_count = 0
     deferred = None
+    # the update guard of the GPU path (see the loop): only torch's fused SGD takes it; with another optimizer (--foreach_sgd,
+    # a caller's own) a non-finite loss still stops the run one step late, that step's update applied
+    guard = None
+    if isinstance(optimizer, torch.optim.SGD) and all(g.get("fused") for g in optimizer.param_groups) and not hasattr(optimizer, "found_inf"):
+        guard = torch.empty(0)
     for images_CPU, targets, blur_dicts in metric_logger.log_every(data_loader, print_freq, header):
         images_GPU, targets_GPU, psfs_GPU, thetas, l1, l2, tables = _to_device(
             images_CPU, targets, blur_dicts, device, blur_train, want_tables=gpu_blur or expand_target_boxes)
@@ -282,6 +287,18 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
         logged = _to_host_async(losses_reduced, loss_dict_reduced)
 
         lr_before = optimizer.param_groups[0]["lr"]        # what the reference's writer logs: read ahead of the warm-up step (:142)
+        checked = logged[2] is None
+        if checked:
+            # tensors on the host: nothing to overlap -- the reference's order exactly (scalars, finite-loss check, THEN the update)
+            _log_step(metric_logger, writer, logged, lr_before, None, iteration_count, epoch, len(data_loader), print_freq, update_meters=False)
+        elif guard is not None:
+            # On the GPU the loss is read one step late (below); the UPDATE must not be: torch's fused SGD skips its step when the
+            # `found_inf` tensor it is handed is non-zero (the hook GradScaler uses), so a non-finite loss -- and every step
+            # behind it, until the host has seen it and exits -- leaves the weights as they were, which is the state the
+            # reference exits in (engine.py:145-148 sits in front of zero_grad / backward / step).  No host synchronisation.
+            bad = torch.isfinite(losses_reduced.detach()).logical_not().to(torch.float32).reshape(1)
+            guard = bad if guard.numel() == 0 else torch.maximum(guard, bad)
+            optimizer.found_inf = guard
         optimizer.zero_grad()
         losses.backward()
         optimizer.step()
@@ -293,21 +310,24 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
         # between forward and backward, engine.py:131-148: the host waits for the forward pass and the GPU idles while
         # the backward pass is issued.  A plain `.item()` here would be no better: its copy queues up behind everything
         # enqueued so far and drains the stream once per step -- 3-4 ms of idle GPU until the next step's first kernels.)
-        # A non-finite loss still stops the run, one step later; the last step is checked behind the loop.
+        # A non-finite loss still stops the run, one step later (its update and the next one skipped: `guard` above); the last
+        # step is checked behind the loop.
         if deferred is not None:
             _log_step(*deferred)
         deferred = (metric_logger, writer, logged, lr_before, optimizer.param_groups[0]["lr"],
-                    iteration_count, epoch, len(data_loader), print_freq)
+                    iteration_count, epoch, len(data_loader), print_freq, True, not checked)
         # reference :160-162, literally: `early_stop=False` (the signature's default) compares as 0 and ends the epoch
         # after two iterations; train.py passes --early_stop (None unless given).  The iteration that breaks is
         # logged and checked but, as in the reference, not entered into the meters.
         if early_stop is not None and iteration_count > early_stop:
-            _log_step(*deferred, update_meters=False)
+            _log_step(*deferred[:9], update_meters=False, check=deferred[10])
             deferred = None
             break
         iteration_count += 1
     if deferred is not None:
         _log_step(*deferred)
+    if guard is not None and hasattr(optimizer, "found_inf"):
+        del optimizer.found_inf
     return metric_logger
 
 
@@ -324,21 +344,21 @@ def _to_host_async(total, loss_dict):
     return keys, host, done
 
 
-def _log_step(metric_logger, writer, logged, lr_before, lr_after, iteration_count, epoch, n_iter, print_freq, update_meters=True):
+def _log_step(metric_logger, writer, logged, lr_before, lr_after, iteration_count, epoch, n_iter, print_freq, update_meters=True, check=True):
     """reference engine.py:131-158: TensorBoard scalars every 500 iterations (learning rate as it was BEFORE this
-    iteration's warm-up step), exit on a non-finite loss, meters (learning rate AFTER the step)."""
+    iteration's warm-up step), exit on a non-finite loss (`check`), meters (learning rate AFTER the step; `update_meters`)."""
     keys, host, done = logged
     if done is not None:
         done.synchronize()
     values = host.tolist()
     loss_value, loss_dict_reduced = values[0], dict(zip(keys, values[1:]))
-    if iteration_count % 500 == 0 and writer is not None and utils.is_main_process() and iteration_count % print_freq == 0:
+    if check and iteration_count % 500 == 0 and writer is not None and utils.is_main_process() and iteration_count % print_freq == 0:
         step = iteration_count + epoch * n_iter
         for key, v in loss_dict_reduced.items():
             writer.add_scalar("losses/" + key, v, step)
         writer.add_scalar("losses/overallLoss", loss_value, step)
         writer.add_scalar("learningRate", lr_before, step)
-    if not math.isfinite(loss_value):                                # reference :145-148
+    if check and not math.isfinite(loss_value):                      # reference :145-148
         print("Loss is {}, stopping training".format(loss_value))
         print(loss_dict_reduced)
         sys.exit(1)

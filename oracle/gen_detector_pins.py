@@ -97,22 +97,27 @@ def _cpu_engine(eng, group=True):
             dist.destroy_process_group()
 
 
-def _run_train(eng, blur, **kw):
+def _run_train(eng, blur, poison_at=None, out_text=None, **kw):
     torch.manual_seed(0)
     np.random.seed(0)
     model = PI.ToyDetector(1)
     opt = torch.optim.SGD(model.parameters(), lr=0.04, momentum=0.9, weight_decay=1e-4)
     model.lr_probe = opt
     writer = PI.RecordingWriter()
-    loader = PI.train_batches(blur)
+    loader = PI.train_batches(blur, poison_at)
     losses = []
     hook = model.register_forward_hook(lambda m, i, o: losses.append({k: float(v.detach()) for k, v in o.items()}))
     buf = io.StringIO()
-    with contextlib.redirect_stdout(buf):
-        eng.train_one_epoch(model, opt, loader, torch.device("cpu"), epoch=kw.pop("epoch", 0), print_freq=2, writer=writer,
-                            distributed_mode=True, blur_train=blur, gpu_blur=blur, expand_target_boxes=blur,
-                            use_custom_image_norm=blur, **kw)
-    hook.remove()
+    try:
+        with contextlib.redirect_stdout(buf):
+            eng.train_one_epoch(model, opt, loader, torch.device("cpu"), epoch=kw.pop("epoch", 0), print_freq=2, writer=writer,
+                                distributed_mode=True, blur_train=blur, gpu_blur=blur, expand_target_boxes=blur,
+                                use_custom_image_norm=blur, **kw)
+    finally:
+        hook.remove()
+        if out_text is not None:
+            out_text.append(buf.getvalue())
+            out_text.append(len(model.calls))
     return model, opt, writer, losses
 
 
@@ -129,6 +134,30 @@ def gen_train(pins, store):
             out[name] = {"steps": len(model.calls), "lr_seen_by_forward": [c["lr"] for c in model.calls],
                          "final_lr": opt.param_groups[0]["lr"], "losses": losses, "scalars": writer.scalars,
                          "calls": [{k: c[k] for k in ("thetas", "lambda1s", "lambda2s", "dtypes", "killWarp")} for c in model.calls]}
+        # a step whose loss is not finite: the reference prints and leaves the process IN FRONT of that step's update (engine.py:145-148)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        text, code = [], None
+        probe = {}
+        saved_step = torch.optim.SGD.step
+
+        def spy(self, *a, **k):          # the optimiser the run used, for its state at the exit
+            probe["opt"] = self
+            return saved_step(self, *a, **k)
+        torch.optim.SGD.step = spy
+        try:
+            _run_train(eng, False, poison_at=2, out_text=text, early_stop=None)
+        except SystemExit as e:
+            code = e.code
+        finally:
+            torch.optim.SGD.step = saved_step
+        opt = probe["opt"]
+        params = [p for g in opt.param_groups for p in g["params"]]
+        for i, p in enumerate(params):
+            store["train_nonfinite_param%d" % i] = p.detach().numpy().copy()
+            store["train_nonfinite_momentum%d" % i] = opt.state[p]["momentum_buffer"].numpy().copy()
+        out["nonfinite"] = {"steps": text[1], "exit_code": code, "lines": [ln for ln in text[0].splitlines() if ln.startswith("Loss is")],
+                            "final_lr": opt.param_groups[0]["lr"]}
     pins["train"] = out
 
 

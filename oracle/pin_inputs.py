@@ -371,14 +371,17 @@ def _target(rs, H, W, n, image_id):
             "image_id": torch.tensor([image_id])}
 
 
-def train_batches(blur):
+def train_batches(blur, poison_at=None):
     """5 batches x 2 images, ragged sizes >= 65 (reflect branch); with `blur`, image 0 of every batch and image 1 of
-    the even ones carry golden PSFs of all three types and of exposures 1/18 ... 1 and 1/25."""
+    the even ones carry golden PSFs of all three types and of exposures 1/18 ... 1 and 1/25.  `poison_at`: one pixel of that
+    batch's first image is +inf (the toy detector's losses of that step are then not finite)."""
     rs = np.random.RandomState(4711)
     loader = ListLoader()
     for k in range(5):
         shapes = [(3, 70 + 2 * k, 90), (3, 80, 75 + k)]
         images = tuple(torch.from_numpy(rs.random_sample(s).astype(np.float32)) for s in shapes)
+        if poison_at == k:
+            images[0][1, 7, 9] = float("inf")
         targets = tuple(_target(rs, s[1], s[2], 3 + (k + j) % 2, 10 * k + j) for j, s in enumerate(shapes))
         if blur:
             dicts = (_blur_dict(rs, k % 3, (k * 2) % 6, True), _blur_dict(rs, (k + 1) % 3, (k + 3) % 6, k % 2 == 0))

@@ -186,6 +186,51 @@ def test_train_one_epoch_equals_the_reference_gpu(pins, arrays, name):
     _check_train(name, torch.device("cuda"), pins, arrays, 1e-5)
 
 
+def _run_nonfinite(device, make_opt):
+    from detectinblur_amd import engine
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = PI.ToyDetector(1).to(device)
+    opt = make_opt(model)
+    model.lr_probe = opt
+    buf = io.StringIO()
+    with pytest.raises(SystemExit) as exit_info, contextlib.redirect_stdout(buf):
+        engine.train_one_epoch(model, opt, PI.train_batches(False, poison_at=2), device, epoch=0, print_freq=2, writer=PI.RecordingWriter(),
+                               distributed_mode=True, early_stop=None)
+    return model, opt, buf.getvalue(), exit_info.value.code
+
+
+def _check_nonfinite(model, opt, text, code, pins, arrays, tol, steps):
+    want = pins["train"]["nonfinite"]
+    assert code == want["exit_code"] == 1
+    assert [ln for ln in text.splitlines() if ln.startswith("Loss is")] == want["lines"]
+    assert len(model.calls) == steps
+    params = [p for g in opt.param_groups for p in g["params"]]
+    for i, p in enumerate(params):      # the weights and the momentum the reference leaves the process with: the bad step's update never applied
+        assert np.allclose(p.detach().cpu().numpy(), arrays["train_nonfinite_param%d" % i], atol=tol, rtol=tol), i
+        assert np.allclose(opt.state[p]["momentum_buffer"].cpu().numpy(), arrays["train_nonfinite_momentum%d" % i], atol=tol, rtol=tol), i
+        assert bool(torch.isfinite(p).all())
+
+
+def test_non_finite_loss_stops_in_front_of_the_update_cpu(pins, arrays):
+    """reference engine.py:145-148: "Loss is nan, stopping training", exit code 1, IN FRONT of that step's zero_grad / backward /
+    step -- with the tensors on the host this loop follows that order literally (three forward passes, two updates)."""
+    model, opt, text, code = _run_nonfinite(torch.device("cpu"), lambda m: torch.optim.SGD(m.parameters(), lr=0.04, momentum=0.9, weight_decay=1e-4))
+    _check_nonfinite(model, opt, text, code, pins, arrays, 1e-6, pins["train"]["nonfinite"]["steps"])
+    assert opt.param_groups[0]["lr"] == pytest.approx(pins["train"]["nonfinite"]["final_lr"], rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_non_finite_loss_leaves_the_reference_s_weights_gpu(pins, arrays):
+    """On the GPU the loss is read one step late (no host synchronisation per step), but the updates of the non-finite step and of
+    the one enqueued behind it are skipped on the device (torch's fused SGD and its `found_inf` input): the process exits with
+    the weights and momentum buffers the reference exits with.  One more forward pass has run by then (four instead of three)."""
+    from detectinblur_amd import utils
+    model, opt, text, code = _run_nonfinite(torch.device("cuda"), lambda m: utils.make_sgd(m.parameters(), lr=0.04, momentum=0.9, weight_decay=1e-4))
+    assert all(g.get("fused") for g in opt.param_groups)
+    _check_nonfinite(model, opt, text, code, pins, arrays, 1e-5, pins["train"]["nonfinite"]["steps"] + 1)
+
+
 # ---- A17: evaluate (reference engine.py:220-416) -----------------------------------------------------------------------------
 
 def _run_eval(name, device, monkeypatch):
