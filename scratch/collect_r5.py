@@ -25,8 +25,7 @@ step = [r for r in rows if "blur_step_f16_kernel<0>" in r["Name"]][0]
 blur = [r for r in rows if "blur_quad_f16_kernel<0, 128, false>" in r["Name"]][0]
 trace = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
 durs = {"step": [], "blur": []}
-tr = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace))
-            if "blur_step_f16_kernel<0>" in r["Kernel_Name"] or "blur_quad_f16_kernel<0, 128, false>" in r["Kernel_Name"])
+tr = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace)))      # EVERY kernel: a run ends at any other launch
 # maximal runs of back-to-back launches of ONE kernel: the roofline loops of bench.py are the longest runs of each
 def longest_run(name):
     best, cur = [], []
@@ -36,7 +35,7 @@ def longest_run(name):
         else:
             best, cur = (cur if len(cur) > len(best) else best), []
     return cur if len(cur) > len(best) else best
-loop_step, loop_blur = longest_run("blur_step_f16_kernel"), longest_run("blur_quad_f16_kernel")
+loop_step, loop_blur = longest_run("blur_step_f16_kernel<0>"), longest_run("blur_quad_f16_kernel<0, 128, false>")
 loop_blur = loop_blur[:1040] if len(loop_blur) > 1040 else loop_blur        # warm roofline loop; the cold rotation follows it
 shutil.copy(stats, os.path.join(root, "profiles", "r5_bench_kernel_stats.csv"))
 line = [l for l in open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines() if l.startswith("{")][-1]
