@@ -7,6 +7,8 @@
 //   2xr2b64  two ds_read2_b64 (the same 32 bytes per lane in two instructions)
 //   4xb32    four ds_read_b32 (half the bytes)
 //   8xb64    eight ds_read_b64 (twice the bytes)
+//   k_arith2 / k_arith6 / k_wait2 / k_sc3_2 / k_sc3_6 / k_vadd2: no LDS reads; the sixteen packed instructions alone with 2 or 6
+//   taps per loop branch, + one s_waitcnt per tap, + the loop's scalar ALU work per tap, + one plain vector instruction per tap
 // Prints shader cycles per wave-tap on a SIMD = launch time x clock / (TAPS x 8), the clock read inside the loop
 // (s_memtime over s_memrealtime, median over the waves).
 #include <hip/hip_runtime.h>
@@ -55,6 +57,34 @@ KERNEL(k_4b64, RD_4B64)
 KERNEL(k_2r2b64, RD_2R2)
 KERNEL(k_4b32, RD_4B32)
 KERNEL(k_8b64, RD_8B64)
+
+// scalar-side variants of the loop without LDS reads: what the instructions AROUND the sixteen packed ones cost
+#define KERNEL2(NAME, BODY, TAPS_PER_ITER)                                                                           \
+  __global__ __launch_bounds__(256, 8) void NAME(unsigned *out, int taps) {                                          \
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                                      \
+    unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;                                         \
+    const unsigned w = 0x3c003c00u, base = 0;                                                                        \
+    unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane(taps / TAPS_PER_ITER);                                   \
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();              \
+    asm volatile("s_mov_b32 s20, 0\n\tv_mov_b32 v32, 0x3c003c00\n\tv_mov_b32 v33, v32\n\tv_mov_b32 v34, v32\n\tv_mov_b32 v35, v32\n\tv_mov_b32 v36, v32\n\tv_mov_b32 v37, v32\n\tv_mov_b32 v38, v32\n\tv_mov_b32 v39, v32\n\t" \
+                 "v_mov_b32 v40, v32\n\tv_mov_b32 v41, v32\n\tv_mov_b32 v42, v32\n\tv_mov_b32 v43, v32\n\tv_mov_b32 v44, v32\n\tv_mov_b32 v45, v32\n\tv_mov_b32 v46, v32\n\tv_mov_b32 v47, v32\n\t" \
+                 "L" #NAME "%=:\n\t" BODY                                                                              \
+                 "s_sub_u32 %10, %10, 1\n\ts_cmp_lg_u32 %10, 0\n\ts_cbranch_scc1 L" #NAME "%=\n\t"                     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                     \
+                 : "v"(w), "v"(base), "s"(cnt)                                                                         \
+                 : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "s20", "scc", "memory"); \
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();              \
+    if (lane == 0) { out[(blockIdx.x * 4 + wave) * 4] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7; out[(blockIdx.x * 4 + wave) * 4 + 1] = (unsigned)(c1 - c0); out[(blockIdx.x * 4 + wave) * 4 + 2] = (unsigned)(r1 - r0); } \
+  }
+#define SC3 "s_waitcnt lgkmcnt(0)\n\ts_add_u32 s20, s20, 8\n\ts_and_b32 s20, s20, 0xbf\n\t"
+#define SC1 "s_waitcnt lgkmcnt(0)\n\t"
+KERNEL2(k_arith2, ARITH_X ARITH_Y, 2)                                       // two taps per branch, nothing else
+KERNEL2(k_arith6, ARITH_X ARITH_Y ARITH_X ARITH_Y ARITH_X ARITH_Y, 6)       // six taps per branch, nothing else
+KERNEL2(k_wait2, SC1 ARITH_X SC1 ARITH_Y, 2)                                // + one s_waitcnt per tap
+KERNEL2(k_sc3_2, SC3 ARITH_X SC3 ARITH_Y, 2)                                // + waitcnt + two scalar ALU per tap (= k_none's body)
+KERNEL2(k_sc3_6, SC3 ARITH_X SC3 ARITH_Y SC3 ARITH_X SC3 ARITH_Y SC3 ARITH_X SC3 ARITH_Y, 6)
+KERNEL2(k_vadd2, "v_add_u32 v48, s20, %9\n\t" ARITH_X "v_add_u32 v48, s20, %9\n\t" ARITH_Y, 2)   // + one plain vector instruction per tap
+
 __global__ __launch_bounds__(256, 8) void k_clk(unsigned long long *o) {
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - r0 < 2000) {}
@@ -72,5 +102,6 @@ int main() {
     std::sort(clk.begin(), clk.end()); std::sort(life.begin(), life.end()); const double ghz = clk[clk.size() / 2]; \
     printf("%-10s %.2f us per launch of %d taps x 8 waves per SIMD = %.1f ns per wave-tap = %.1f cycles at the measured %.2f GHz (wave life p50 %.1f us)\n", #K, ms * 1e3, taps, ms * 1e6 / (taps * 8.0), ms * 1e6 / (taps * 8.0) * ghz, ghz, life[life.size() / 2]); }
   RUN(k_none) RUN(k_4b64) RUN(k_2r2b64) RUN(k_4b32) RUN(k_8b64) RUN(k_none) RUN(k_4b64)
+  RUN(k_arith2) RUN(k_arith6) RUN(k_wait2) RUN(k_sc3_2) RUN(k_sc3_6) RUN(k_vadd2) RUN(k_arith2) RUN(k_arith6)
   return 0;
 }
