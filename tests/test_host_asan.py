@@ -1,4 +1,4 @@
-"""The hand-written host C code (csrc/host/dib_host.c: MT19937, polar gauss, trajectory walk, PSF splatting, centring, COCO matching) under
+"""The hand-written host C code (csrc/host/dib_host.c: MT19937, polar gauss, trajectory walk, PSF splatting, centring, COCO matching, polygon masks) under
 AddressSanitizer + UndefinedBehaviorSanitizer: `make -C detectinblur_amd/csrc asan` builds libdib_host_asan.so, and the
 host-side parity tests run against it in a child interpreter with libasan preloaded.  Any report aborts the child."""
 import os
@@ -22,7 +22,10 @@ def test_host_library_is_clean_under_asan_and_ubsan():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_host_native.py"),
                         os.path.join(ROOT, "tests", "test_transforms_cpu.py"),
                         os.path.join(ROOT, "tests", "test_coco_eval.py") + "::test_native_matching_equals_the_interpreted_loop_nest",
-                        os.path.join(ROOT, "tests", "test_coco_eval.py") + "::test_native_accumulate_equals_the_interpreted_form"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+                        os.path.join(ROOT, "tests", "test_coco_eval.py") + "::test_native_accumulate_equals_the_interpreted_form",
+                        os.path.join(ROOT, "tests", "test_masks.py") + "::test_object_masks_equal_the_reference",
+                        os.path.join(ROOT, "tests", "test_masks.py") + "::test_random_polygons_against_the_reference_library",
+                        os.path.join(ROOT, "tests", "test_masks.py") + "::test_convert_coco_polys_to_mask_target"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = (r.stdout[-3000:] + r.stderr[-3000:])
     assert r.returncode == 0, tail
     assert "passed" in r.stdout and "AddressSanitizer" not in tail and "runtime error" not in tail
