@@ -92,8 +92,11 @@ def _write_coco(root, split="val"):
     k = 1
     def add(img, bbox, cat, crowd=0):
         nonlocal k
+        x, y, bw, bh = bbox          # outline: the box itself as a four-point polygon; the crowd object as an uncompressed RLE; one none
+        seg = {"size": list(sizes[img]), "counts": [30, 50, sizes[img][0] * sizes[img][1] - 80]} if crowd else \
+            ([] if cat == 90 else [[x, y, x + bw, y, x + bw, y + bh, x, y + bh]])
         anns.append({"id": k, "image_id": img, "bbox": bbox, "category_id": cat, "area": bbox[2] * bbox[3], "iscrowd": crowd,
-                     "segmentation": []})
+                     "segmentation": seg})
         k += 1
     add(11, [10.5, 20.25, 40.0, 30.0], 3)
     add(11, [100.0, 60.0, 50.0, 50.0], 18)          # sticks out of the 120 x 96 image: clamped
@@ -120,6 +123,14 @@ def test_coco_detection_reads_a_real_tree(tmp_path):
     assert torch.equal(tgt["boxes"], torch.tensor([[10.5, 20.25, 50.5, 50.25], [100.0, 60.0, 120.0, 96.0]]))
     assert tgt["labels"].tolist() == [3, 18] and tgt["labels"].dtype == torch.int64
     assert tgt["iscrowd"].tolist() == [0, 0, 0] and tgt["area"].tolist() == [1200.0, 2500.0, 0.0]     # not filtered by `keep`
+    # masks of the two kept objects (reference coco_utils.py:34-49), flipped with the image when the flip transform fires
+    assert tgt["masks"].dtype == torch.uint8 and tuple(tgt["masks"].shape) == (2, 96, 120)
+    m0 = tgt["masks"][0].numpy()
+    ys, xs = np.nonzero(m0)
+    assert (xs.min(), xs.max(), ys.min(), ys.max()) == (11, 50, 20, 49) and m0.sum() == 40 * 30      # the polygon (10.5, 20.25) .. (50.5, 50.25) as pycocotools fills it
+    assert tgt["masks"][1][60:, 100:].all() and tgt["masks"][1].sum() == 20 * 36                      # clipped by the image
+    _, t5, _ = ds[0]                                                         # image 5: an object without an outline
+    assert tuple(t5["masks"].shape) == (1, 110, 100) and int(t5["masks"].sum()) == 0
     img, tgt, _ = ds[3]                                                      # image 77: nothing annotated
     assert tuple(tgt["boxes"].shape) == (0, 4) and tgt["labels"].numel() == 0
     # training drops 42 (only an empty box) and 77 (nothing)
