@@ -126,16 +126,18 @@ def test_two_runs_of_evaluate_main_print_identical_coco_stats(tmp_path):
     (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
     a = _run_child(_gpu_children.evaluate_main_digest, tmp_path / "a", argv)
     b = _run_child(_gpu_children.evaluate_main_digest, tmp_path / "b", argv)
-    # First what the two processes' kernel choices rested on: a difference HERE is MIOpen / PyTorch choosing other kernels (a find
-    # step for a shape the shipped data does not hold, ranked differently; another MIOpen build ignoring the shipped files), not a
-    # defect of the evaluation path -- and it is reported as that, not as 180 differing statistic lines.
+    # What the two processes' kernel choices rested on is compared FIRST: when the outputs differ AND the choices did (a find step for a
+    # shape the shipped data does not hold, ranked differently by the two processes; another MIOpen build ignoring the shipped files),
+    # the failure is MIOpen / PyTorch choosing other kernels, not a defect of the evaluation path -- and it says so, instead of 180
+    # differing statistic lines.  (tests/test_kernel_choices_gpu.py is where a stack the shipped data does not belong to fails.)
     ka, kb = a["kernel_choice"], b["kernel_choice"]
-    assert ka["installed"] and kb["installed"], "evaluate.main did not install the shipped kernel-choice data"
-    assert ka["miopen_foreign_files"] == [] and kb["miopen_foreign_files"] == [], (
-        "MIOpen wrote a db under another name: the shipped find-db belongs to another MIOpen build", ka, kb)
-    assert ka["tunableop_validators_match"] and kb["tunableop_validators_match"], ("the shipped TunableOp results are not this PyTorch's", ka, kb)
-    assert ka == kb, ("kernel-choice drift between the two processes (MIOpen find results appended to the private db: %s / %s bytes): "
-                      "the runs did not use the same kernels" % (ka["miopen_db_growth_bytes"], kb["miopen_db_growth_bytes"]), ka, kb)
+    drift = None
+    if ka != kb or not ka["installed"] or ka["miopen_foreign_files"] or not ka["tunableop_validators_match"]:
+        drift = ("the two processes did not rest on the same kernel choices (MIOpen find results appended to the private db: %s / %s bytes; "
+                 "foreign db files %s; TunableOp validators match: %s): a kernel-choice drift, not a defect of the evaluation path -- %r vs %r"
+                 % (ka["miopen_db_growth_bytes"], kb["miopen_db_growth_bytes"], ka["miopen_foreign_files"], ka["tunableop_validators_match"], ka, kb))
+    same = a["stat_lines"] == b["stat_lines"] and all(a["cells"].get(c) == b["cells"].get(c) for c in a["cells"])
+    assert same or drift is None, drift
     assert len(a["stat_lines"]) == 12 * 15 and a["stat_lines"] == b["stat_lines"]
     assert sorted(a["cells"]) == sorted(b["cells"]) and len(a["cells"]) == 15
     for cell in a["cells"]:
