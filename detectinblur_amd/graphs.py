@@ -41,9 +41,12 @@ class GraphCache(object):
     then on.  A shape is captured when it is seen for the `capture_after`-th time (rare shapes of a varied dataset stay eager
     instead of evicting a common shape's graph: the reference evaluates COCO at batch 1, dozens of padded shapes).  All graphs
     of one cache share ONE memory pool: they are replayed one at a time and their outputs are consumed in stream order before
-    the next replay, so the pool holds the largest shape's activations, not the sum over the shapes."""
+    the next replay, so the pool holds the largest shape's activations, not the sum over the shapes (what a graph keeps for itself
+    are its input and output buffers: ~0.1 GB for the detector's trunk at batch 1).  `limit`: real COCO images reach ~50 padded
+    input shapes after the transform (the grid `scratch/fill_dbs_grid.sh` fills the kernel-choice data for); a cache smaller
+    than that would evict and recapture (three forward passes each) all through an evaluation."""
 
-    def __init__(self, fn, limit=16, capture_after=2):
+    def __init__(self, fn, limit=64, capture_after=2):
         self.fn, self.limit, self.capture_after = fn, limit, capture_after
         self.graphs, self.seen, self.pool = {}, {}, None
 
