@@ -432,8 +432,17 @@ static void dib_runs_or(const unsigned *runs, long n_runs, long h, long w, unsig
   for (long r = 0; r < n_runs && at < total; ++r, v = !v) {
     unsigned long long end = at + runs[r];
     if (end > total) end = total;
-    if (v)
-      for (unsigned long long p = at; p < end; ++p) mask[(p % (unsigned long long)h) * (unsigned long long)w + p / (unsigned long long)h] = 1;
+    if (v) {          /* column by column: one division per column segment, not per pixel */
+      unsigned long long p = at;
+      while (p < end) {
+        const unsigned long long x = p / (unsigned long long)h, y0 = p % (unsigned long long)h;
+        unsigned long long n = (unsigned long long)h - y0;
+        if (n > end - p) n = end - p;
+        unsigned char *col = mask + y0 * (unsigned long long)w + x;
+        for (unsigned long long k = 0; k < n; ++k) col[k * (unsigned long long)w] = 1;
+        p += n;
+      }
+    }
     at = end;
   }
 }
