@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("DIB_HIP_LIB") or os.path.join(_HERE, "libdib_hip.so")
 
 DIB_F16, DIB_F32 = 0, 1
 DIB_ACC_BITEXACT, DIB_ACC_FP32, DIB_ACC_FMA16 = 0, 1, 2
-DIB_EINVAL, DIB_ESHAPE, DIB_EHIP, DIB_ENOT128, DIB_ECAPTURE = -1, -2, -3, -4, -5
+DIB_EINVAL, DIB_ESHAPE, DIB_EHIP, DIB_ENOT128, DIB_ECAPTURE, DIB_ETIMEOUT = -1, -2, -3, -4, -5, -6
 DIB_STEP_PSFS_COMPLETE, DIB_STEP_LARGE_WINDOW = 1, 2
 DIB_COMPACT_LARGE_WINDOW, DIB_WINDOW_LARGE = 8, 0x100
 
@@ -45,6 +45,12 @@ _SIGNATURES = {
     "dib_blur_step_packed": (ctypes.c_int, [_c_void_pp, _c_int_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "dib_blur_step_release": (ctypes.c_int, []),
+    "dib_blur_step_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "dib_blur_step_ws": (ctypes.c_int, [_c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        _c_void_pp, _c_void_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int,
+                                        ctypes.c_void_p]),
+    "dib_device_status": (ctypes.c_int, [ctypes.c_int]),
     "dib_normalize_pad": (ctypes.c_int, [_c_void_pp, ctypes.c_int, _c_int_p, _c_int_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p]),
@@ -134,6 +140,11 @@ class DibError(RuntimeError):
         self.code = code
 
 
+class DibStepTimeout(DibError):
+    """DIB_ETIMEOUT: an EARLIER blur step on this device gave up waiting inside its launch (include/dib.h, "Device status"); its
+    images are incomplete, nothing was launched by the call that reports it, and the device is on two launches per step from here."""
+
+
 def lib():
     """Loads libdib_hip.so once.  Raises if it has not been built (python __graft_entry__.py)."""
     global _lib
@@ -145,7 +156,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.dib_abi_version() != 6:
+        if l.dib_abi_version() != 7:
             raise ImportError("libdib_hip.so ABI version mismatch")
         _lib = l
     return _lib
@@ -153,7 +164,8 @@ def lib():
 
 def check(code):
     if code != 0:
-        raise DibError(code, lib().dib_last_error().decode("utf-8", "replace"))
+        text = lib().dib_last_error().decode("utf-8", "replace")
+        raise (DibStepTimeout if code == DIB_ETIMEOUT else DibError)(code, text)
 
 
 _raw_stream = None

@@ -10,6 +10,19 @@ from . import _lib
 _DT = {torch.float16: _lib.DIB_F16, torch.float32: _lib.DIB_F32}
 
 
+def _reissuing(call):
+    """Runs `call()` (a library entry point that launches a blur).  DIB_ETIMEOUT from it means that an EARLIER blur step on this
+    device gave up waiting inside its single launch (include/dib.h, "Device status"): that step's images are incomplete, THIS
+    call launched nothing, and the library has put the device on compaction + blur as two launches.  The process survives: the
+    condition is reported as a RuntimeWarning carrying the library's text and the call is issued again."""
+    rc = call()
+    if rc == _lib.DIB_ETIMEOUT:
+        import warnings
+        warnings.warn(_lib.lib().dib_last_error().decode("utf-8", "replace"), RuntimeWarning, stacklevel=3)
+        rc = call()
+    return rc
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -217,10 +230,10 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
     _await(tables)
     if tables.large:
         acc_mode |= _lib.DIB_WINDOW_LARGE          # the tables hold the large window's segments and offsets
-    _lib.check(_lib.lib().dib_sparse_blur(_lib.ptr_array(ins_p), _lib.ptr_array(outs_p), _lib.int_array(Cs),
-                                          _lib.int_array(Hs), _lib.int_array(Ws), _lib.int_array(table_index),
-                                          len(images), _DT[dt], tables.buf.data_ptr(), tables.count, tables.K, acc_mode,
-                                          _stream(dev)))
+    args = (_lib.ptr_array(ins_p), _lib.ptr_array(outs_p), _lib.int_array(Cs), _lib.int_array(Hs), _lib.int_array(Ws),
+            _lib.int_array(table_index), len(images), _DT[dt], tables.buf.data_ptr(), tables.count, tables.K, acc_mode, _stream(dev))
+    fn = _lib.lib().dib_sparse_blur
+    _lib.check(_reissuing(lambda: fn(*args)))
     return outs
 
 
@@ -360,7 +373,7 @@ def blur_step(images, table_index, psfs, normalize=True, acc_mode=_lib.DIB_ACC_B
     pa = _lib.ptr_array(ptrs + ins_p + outs_p)
     ia = _lib.int_array(Cs + Hs + Ws + list(table_index))
     stream = _stream(dev)
-    rc = l.dib_blur_step_packed(pa, ia, _DT[pdt], len(ptrs), K, int(bool(normalize)), n, _DT[dt], acc_mode, None, flags, stream)
+    rc = _reissuing(lambda: l.dib_blur_step_packed(pa, ia, _DT[pdt], len(ptrs), K, int(bool(normalize)), n, _DT[dt], acc_mode, None, flags, stream))
     if rc == _lib.DIB_ECAPTURE:            # the current stream is being captured: tables from the capture's pool
         tabs = TapTables(K, len(ptrs), dev, large_window)
         rc = l.dib_blur_step_packed(pa, ia, _DT[pdt], len(ptrs), K, int(bool(normalize)), n, _DT[dt], acc_mode, tabs.buf.data_ptr(),

@@ -31,8 +31,35 @@
 #include <mutex>
 #include <vector>
 #include <stdlib.h>
+#include <string.h>
+
+// ---- the device's status word: what a kernel of this file writes instead of trapping ---------------------------------
+// Two things can go wrong inside a launch that the host cannot see when it enqueues it: an in-launch hand-off that does not
+// arrive within its poll budget (blur_step_f16_kernel) and a tap table compacted for the other LDS window geometry.  A trap
+// would take the whole GPU context -- a training job's -- with it.  Instead the workgroup stores a code into a block of PINNED
+// HOST memory the library owns (one per device, set up by prepare_device; the pointer sits in this code-object global, so no
+// kernel carries it in a register) and ends; its tile stays unwritten.  The next dib_blur_step / dib_sparse_blur call on the
+// device finds the code without any synchronisation, reports it (DIB_ETIMEOUT / DIB_EINVAL) and, for a hand-off, takes the
+// single launch out of service for that device: include/dib.h, "Device status".
+extern "C" { __device__ __attribute__((used)) unsigned *dib_status_word = nullptr; }
+#define DIB_STATUS_HANDOFF 1u     /* word 0: code, word 1: detail (the hand-off's tag / the table's geometry word) */
+#define DIB_STATUS_GEOMETRY 2u
+#define DIB_STATUS_WORDS 16
+#ifdef DIB_STEP_POLLSTATS
+// Diagnostic build only (scratch/t_step_contention.py): the most polls any workgroup of any launch needed, [0] for its PSF's first
+// segment, [1] for the counter in front of its first tap loop; read and cleared through dib_debug_poll_stats.
+extern "C" { __device__ __attribute__((used)) unsigned dib_poll_stats[4] = {0, 0, 0, 0}; }
+#endif
 
 namespace dib {
+
+__device__ __forceinline__ void report_and_exit(unsigned code, unsigned detail) {
+  typedef __attribute__((address_space(1))) unsigned gu32;
+  gu32 *st = (gu32 *)(size_t)*(unsigned *volatile *)&dib_status_word;
+  __hip_atomic_store(st + 1, detail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(st, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_endpgm();
+}
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
@@ -678,8 +705,10 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     seg = make_uint4((unsigned)r, (unsigned)(r >> 32), (unsigned)(r >> 64), (unsigned)(r >> 96));
     nsegs = (int)(unsigned)(hd >> 96);
     // a table compacted for the other window geometry (include/dib.h: DIB_COMPACT_LARGE_WINDOW / DIB_WINDOW_LARGE must agree)
-    // holds offsets for another LDS pitch: garbage pixels, silently.  Stop instead (the launch fails: hipErrorLaunchFailure).
-    if (((unsigned)(hd >> 32) >> 16) != (L ? 1u : 0u)) __builtin_trap();
+    // holds offsets for another LDS pitch: garbage pixels, silently.  The workgroup leaves its tile unwritten instead and says so in
+    // the device's status word (the next call on the device returns DIB_EINVAL; blur_ops.sparse_blur checks on the host first).
+    // (the step's single launch compacts its own tables, for the standard window: nothing to check there)
+    if constexpr (!STEP) { if (((unsigned)(hd >> 32) >> 16) != (L ? 1u : 0u)) report_and_exit(DIB_STATUS_GEOMETRY, (unsigned)(hd >> 32)); }
   }
   static_assert(HDR_NSEGS == 7 && HDR_K == 5 && HDR_WORDS == 8, "header words 4..7 in the asm above");
   const unsigned long long la = (unsigned long long)(tab + table_ltaps_q_off(K));
@@ -938,7 +967,19 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
   if constexpr (FLAT) {
     typedef int i16v __attribute__((ext_vector_type(16)));
     const i16v bb = *reinterpret_cast<const i16v *>(fb.begin[blockIdx.x & 7]);
-    if (entry >= bb[15]) return;
+    const int len = bb[15] & 0x3fffffff;      // bit 30: walk every other stride backwards (off only in A/B runs: dib_debug_set_flat_snake)
+    if (entry >= len) return;
+    // Boustrophedon over the dispatcher's round robin.  A ragged batch is ONE round of workgroups, all resident at once, and the
+    // hardware deals a list's workgroups to its XCD's 32 CUs in turn: CU j runs workgroups j, j + 32, j + 64, ... of the list
+    // (measured: the per-CU tap sums of profiles/r5_native_timeline.txt are exactly those of that model).  The list is sorted by
+    // weight (heaviest image first), so dealt straight CU 0 gets the heaviest entry of EVERY stride of 32 -- and the left-over
+    // partial stride on top: 277 taps against a mean of 241 on the native-size batch.  Every other full stride is therefore
+    // walked backwards (the last full one always, so that the partial stride's workgroups, which go to CUs 0, 1, ... whatever is
+    // done, meet the lightest entries of the stride before): 259.  Which TILE a workgroup computes is all that changes.
+    {
+      const int row = entry >> 5, full = len >> 5;
+      if ((bb[15] >> 30) && row < full && ((full - 1 - row) & 1) == 0) entry ^= 31;
+    }
     int start = bb[0];
     img_i = 0;
 #pragma unroll
@@ -1006,10 +1047,12 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
 //   counter is monotonic) and falls back to the sc1 poll; early ones must not do that (they would leave the stale line in the
 //   scalar cache for the rest of the launch).
 //   Forward progress: the compacting workgroups have the grid's lowest indices and are dispatched first (observed dispatch
-//   order, relied on by every decoupled look-back scan); a poll that does not succeed within ~1 s traps instead of hanging.
+//   order, relied on by every decoupled look-back scan; nothing the hardware promises).  A poll that does not succeed within its
+//   budget (StepSync::poll_budget, ~1 s) neither hangs nor traps: the workgroup reports DIB_STATUS_HANDOFF through the device's
+//   status word and ends, the host finds the word on its next call and takes the single launch out of service (dib_step.hip).
 // =============================================================================================
 constexpr unsigned STEP_EARLY = 4096;
-constexpr int STEP_LDS_EXTRA = 16;      // {sync pointer, target} for StepWait, behind the window (19,728 B: still eight workgroups per CU)
+constexpr int STEP_LDS_EXTRA = 16;      // {sync pointer, target, poll budget} for StepWait, behind the window (19,728 B: still eight workgroups per CU)
 #ifdef DIB_STEP_STAMPS
 // Diagnostic build only (scratch/t_step_stamps.py): 100 MHz wall-clock stamps of the compacting workgroups (8 words each) and of
 // the blur workgroups of grid row 0 (4 words each, behind them).
@@ -1019,26 +1062,29 @@ __device__ unsigned long long *g_step_stamps;
 // nearly always been reached, so a fresh value lands in the scalar cache; a stale one only costs the sc1 polls behind it).
 // The counter's copy is chosen by the XCD the workgroup runs on (a hardware register).
 struct StepWait {
-  unsigned lds_words;     // LDS byte address of {sync lo, sync hi, target}, written by the kernel in front of the tile function
-  // ONE asm statement on the registers the tap loops clobber anyway (s[36:41], v[45:48]: free between two of them); the three
+  unsigned lds_words;     // LDS byte address of {sync lo, sync hi, target, poll budget}, written by the kernel in front of the tile function
+  // ONE asm statement on the registers the tap loops clobber anyway (s[36:41], v[44:48]: free between two of them); the four
   // words it needs wait in 16 bytes of LDS behind the window, not in scalar registers: the kernel runs at 78 of the 80 that
   // eight waves per SIMD allow, and three more live across the window fill spilled.
-  //   s[36:37] = sync + 128 * XCD, s38 = target; ready when (int)(counter - target) >= 0: first through the scalar cache,
-  //   then (rare) sc1 vector polls of the same copy, ~2^21 of them before the trap.
+  //   s[36:37] = sync + 128 * XCD, s38 = target, s39 = poll budget; ready when (int)(counter - target) >= 0: first through the
+  //   scalar cache, then (rare) sc1 vector polls of the same copy.  A wave whose budget runs out (StepSync::poll_budget: ~1 s)
+  //   does not trap: it writes DIB_STATUS_HANDOFF and the launch's tag into the device's status word (pinned host memory, found
+  //   through the code object's `dib_status_word`) and ends; dib_blur_step reports it on its next call (include/dib.h).
   __device__ __forceinline__ void operator()() const {
     static_assert(STEP_REPLICA_WORDS * 4 == 128, "the shift below");
     asm volatile(
         "v_mov_b32 v48, %0\n\t"
         "ds_read_b64 v[46:47], v48\n\t"
-        "ds_read_b32 v45, v48 offset:8\n\t"
+        "ds_read_b64 v[44:45], v48 offset:8\n\t"
         "s_getreg_b32 s39, hwreg(20, 0, 3)\n\t"              /* HW_REG_XCC_ID[2:0] */
         "s_lshl_b32 s39, s39, 7\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_readfirstlane_b32 s36, v46\n\t"
         "v_readfirstlane_b32 s37, v47\n\t"
-        "v_readfirstlane_b32 s38, v45\n\t"
+        "v_readfirstlane_b32 s38, v44\n\t"
         "s_add_u32 s36, s36, s39\n\t"
         "s_addc_u32 s37, s37, 0\n\t"
+        "v_readfirstlane_b32 s39, v45\n\t"
         "s_load_dword s40, s[36:37], 0x0\n\t"
         "s_mov_b32 s41, 0\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
@@ -1056,14 +1102,38 @@ struct StepWait {
         "s_cbranch_scc0 Ldibw_done%=\n\t"
         "s_sleep 2\n\t"
         "s_add_u32 s41, s41, 1\n\t"
-        "s_cmp_lt_u32 s41, 0x200000\n\t"
+        "s_cmp_lt_u32 s41, s39\n\t"
         "s_cbranch_scc1 Ldibw_poll%=\n\t"
-        "s_trap 2\n\t"
-        "Ldibw_done%=:"
+        /* budget spent: {DIB_STATUS_HANDOFF, tag} -> the status word, and this wave ends (the s_add's literal sits 4 bytes, the
+           s_addc's 12 bytes behind the address s_getpc returns: the offsets hipcc itself emits for this sequence) */
+        "s_getpc_b64 s[36:37]\n\t"
+        "s_add_u32 s36, s36, dib_status_word@rel32@lo+4\n\t"
+        "s_addc_u32 s37, s37, dib_status_word@rel32@hi+12\n\t"
+        "s_load_dwordx2 s[36:37], s[36:37], 0x0\n\t"
+        "v_mov_b32 v47, s38\n\t"
+        "v_mov_b32 v46, 1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "global_store_dword v48, v47, s[36:37] offset:4 sc0 sc1\n\t"
+        "global_store_dword v48, v46, s[36:37] sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_endpgm\n\t"
+        "Ldibw_done%=:\n\t"
+#ifdef DIB_STEP_POLLSTATS
+        "s_cmp_eq_u32 s41, 0\n\t"
+        "s_cbranch_scc1 Ldibw_nostat%=\n\t"
+        "s_getpc_b64 s[36:37]\n\t"
+        "s_add_u32 s36, s36, dib_poll_stats@rel32@lo+4\n\t"
+        "s_addc_u32 s37, s37, dib_poll_stats@rel32@hi+12\n\t"
+        "v_mov_b32 v47, s41\n\t"
+        "v_mov_b32 v48, 0\n\t"
+        "global_atomic_umax v48, v47, s[36:37] offset:4\n\t"
+        "Ldibw_nostat%=:\n\t"
+#endif
         :: "s"(lds_words)
-        : "s36", "s37", "s38", "s39", "s40", "s41", "v45", "v46", "v47", "v48", "scc", "memory");
+        : "s36", "s37", "s38", "s39", "s40", "s41", "v44", "v45", "v46", "v47", "v48", "scc", "memory");
   }
 };
+static_assert(DIB_STATUS_HANDOFF == 1u, "the v_mov_b32 v46, 1 above");
 
 template <int ACC>
 __global__ __launch_bounds__(256, 8) void blur_step_f16_kernel(BlurBatch batch, StepSync sy, PsfPtrs psfs) {
@@ -1077,7 +1147,7 @@ __global__ __launch_bounds__(256, 8) void blur_step_f16_kernel(BlurBatch batch, 
   // the ONE consumer of the thread-index register in this kernel (dib_compact_dev.h: compact_psf_f16_wg256)
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   if (blockIdx.x < (unsigned)sy.ncx) {
-    if (blockIdx.y == 0 && blockIdx.x < (unsigned)sy.n_psf) {
+    if (blockIdx.y == 0 && blockIdx.x < (unsigned)sy.n_psf && !(sy.flags & COMPACT_DEBUG_NOSIGNAL)) {
       unsigned *rec = sy.rec + (size_t)blockIdx.x * (STEP_REPLICAS * STEP_REC_WORDS);
 #ifdef DIB_STEP_STAMPS
       unsigned long long *dbg = *(unsigned long long *volatile *)&g_step_stamps;
@@ -1122,7 +1192,13 @@ __global__ __launch_bounds__(256, 8) void blur_step_f16_kernel(BlurBatch batch, 
   uint4 seg0 = make_uint4(0, 0, 0, 0);
   if (early) {   // ---- the first segment of this image's PSF, from the compaction's early record (sc1 polls of one copy) ----
     const unsigned long long *pr = reinterpret_cast<const unsigned long long *>(sy.rec + ((size_t)d.table * STEP_REPLICAS + (blockIdx.x & (STEP_REPLICAS - 1))) * STEP_REC_WORDS);
+#ifdef DIB_STEP_POLLSTATS
+    unsigned pspins = 0;
+#endif
     for (unsigned spins = 0;; ++spins) {
+#ifdef DIB_STEP_POLLSTATS
+      pspins = spins;
+#endif
       const unsigned long long ra = __hip_atomic_load(pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned long long rb = __hip_atomic_load(pr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned ta = __builtin_amdgcn_readfirstlane((unsigned)(ra >> 32)), tb = __builtin_amdgcn_readfirstlane((unsigned)(rb >> 32));
@@ -1132,14 +1208,18 @@ __global__ __launch_bounds__(256, 8) void blur_step_f16_kernel(BlurBatch batch, 
         seg0 = make_uint4(0u, a & 0xffffu, b2 >> 16, b2 & 0xffffu);
         break;
       }
-      if (spins > (1u << 21)) __builtin_trap();
+      if (spins > sy.poll_budget) report_and_exit(DIB_STATUS_HANDOFF, sy.target);      // no trap: see dib_status_word
       __builtin_amdgcn_s_sleep(2);
     }
+#ifdef DIB_STEP_POLLSTATS
+    if (pspins && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicMax(&dib_poll_stats[0], pspins);
+#endif
     // what StepWait needs, into the 16 bytes of LDS behind the window (every wave's lane 0 writes the same three words)
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
       nlds[QLDS_BYTES / 4] = (unsigned)(unsigned long long)sy.sync;
       nlds[QLDS_BYTES / 4 + 1] = (unsigned)((unsigned long long)sy.sync >> 32);
       nlds[QLDS_BYTES / 4 + 2] = sy.target;
+      nlds[QLDS_BYTES / 4 + 3] = sy.poll_budget;
     }
     asm volatile("" ::: "memory");
   }
@@ -1325,11 +1405,19 @@ extern "C" void dib_debug_set_tile_order(int xcd_bands) { g_xcd_bands = xcd_band
 // compare the two).
 static int g_flat_grid = !(getenv("DIB_FLAT_GRID") && getenv("DIB_FLAT_GRID")[0] == '0');
 extern "C" void dib_debug_set_flat_grid(int on) { g_flat_grid = on ? 1 : 0; }
+// ... and on it, every other stride of 32 workgroups of an XCD's list walked backwards (default; 0 in A/B runs)
+static int g_flat_snake = !(getenv("DIB_FLAT_SNAKE") && getenv("DIB_FLAT_SNAKE")[0] == '0');
+extern "C" void dib_debug_set_flat_snake(int on) { g_flat_snake = on ? 1 : 0; }
 
 namespace {
 // Per-device launch state: the dynamic-LDS opt-in is a per-device function attribute.  Guarded by a mutex: entry
 // points may be called from several host threads.
-struct DeviceState { bool ready = false; };
+struct DeviceState {
+  bool ready = false;
+  volatile unsigned *status = nullptr;   // DIB_STATUS_WORDS words of pinned host memory the device's kernels report into (dib_status_word)
+  bool step_single_off = false;          // a hand-off timed out on this device: dib_blur_step stays on two launches
+  unsigned handoff_timeouts = 0;
+};
 std::mutex g_dev_mutex;
 DeviceState g_dev[64];
 
@@ -1344,6 +1432,14 @@ int prepare_device() {
   std::lock_guard<std::mutex> lock(g_dev_mutex);
   DeviceState &st = g_dev[dev];
   if (!st.ready) {
+    if (!st.status) {   // the status block: coherent pinned host memory, its device address into the code object's global
+      void *host = nullptr, *devp = nullptr;
+      DIB_HIP_CHECK(hipHostMalloc(&host, DIB_STATUS_WORDS * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+      memset(host, 0, DIB_STATUS_WORDS * sizeof(unsigned));
+      DIB_HIP_CHECK(hipHostGetDevicePointer(&devp, host, 0));
+      DIB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(dib_status_word), &devp, sizeof(devp)));
+      st.status = (volatile unsigned *)host;
+    }
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_BITEXACT>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FP32>, LDS_BYTES));
     DIB_HIP_CHECK(opt_in(blur_tiled_f16_kernel<DIB_ACC_FMA16>, LDS_BYTES));
@@ -1370,6 +1466,78 @@ int prepare_device() {
   return DIB_OK;
 }
 }  // namespace
+
+// ---- Device status (include/dib.h) ----------------------------------------------------------------------------------
+// What the host does with a code a kernel left in the status word: report it once, clear it, and -- for a hand-off that timed
+// out -- keep the device on compaction + blur as two launches from then on (whatever held the compacting workgroups back may
+// do so again, and a step that leaves tiles unwritten is worse than one that is 2 us slower).
+static int consume_status_locked(DeviceState &st, int dev, const char *who) {
+  if (!st.status) return DIB_OK;
+  const unsigned code = st.status[0];
+  if (code == 0) return DIB_OK;
+  const unsigned detail = st.status[1];
+  st.status[1] = 0;
+  st.status[0] = 0;
+  if (code == DIB_STATUS_HANDOFF) {
+    st.step_single_off = true;
+    ++st.handoff_timeouts;
+    set_error("%s: an earlier dib_blur_step on device %d ran out of its poll budget waiting for the in-launch tap compaction (tag %u): "
+              "the images of that step are incomplete.  The single launch is now off for this device (compaction + blur as two "
+              "launches from here on); re-issue the batch", who, dev, detail);
+    return DIB_ETIMEOUT;
+  }
+  if (code == DIB_STATUS_GEOMETRY) {
+    set_error("%s: an earlier launch on device %d was handed a tap table compacted for the %s LDS window (DIB_COMPACT_LARGE_WINDOW "
+              "and DIB_WINDOW_LARGE / DIB_STEP_LARGE_WINDOW must agree): its images were left unwritten", who, dev,
+              (detail >> 16) ? "large" : "standard");
+    return DIB_EINVAL;
+  }
+  set_error("%s: unknown device status %u on device %d", who, code, dev);
+  return DIB_EHIP;
+}
+int dib::consume_device_status(const char *who) {
+  int dev = 0;
+  DIB_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return DIB_OK;
+  std::lock_guard<std::mutex> lock(g_dev_mutex);
+  return consume_status_locked(g_dev[dev], dev, who);
+}
+unsigned dib::handoff_generation(int dev) {
+  if (dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lock(g_dev_mutex);
+  return g_dev[dev].handoff_timeouts;
+}
+extern "C" int dib_device_status(int clear) {
+  int dev = 0;
+  DIB_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return DIB_OK;
+  std::lock_guard<std::mutex> lock(g_dev_mutex);
+  if (clear) return consume_status_locked(g_dev[dev], dev, "dib_device_status");
+  const unsigned code = g_dev[dev].status ? g_dev[dev].status[0] : 0u;
+  return code == 0 ? DIB_OK : code == DIB_STATUS_HANDOFF ? DIB_ETIMEOUT : code == DIB_STATUS_GEOMETRY ? DIB_EINVAL : DIB_EHIP;
+}
+// Test hooks: the hand-off's poll budget (1 makes every first-round workgroup of a single launch give up: the compaction takes
+// ~4 us), and whether the single launch is in service on the current device (-1 = ask only; returns the state before the call).
+static unsigned g_poll_budget = 1u << 20;
+static int g_step_nosignal = 0;
+extern "C" void dib_debug_set_step_poll_budget(unsigned polls) { g_poll_budget = polls ? polls : 1u << 20; }
+// the single launch's compacting workgroups do nothing: every blur workgroup of the launch runs out of its poll budget
+extern "C" void dib_debug_set_step_nosignal(int on) { g_step_nosignal = on ? 1 : 0; }
+extern "C" int dib_debug_step_single_launch(int on) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  std::lock_guard<std::mutex> lock(g_dev_mutex);
+  const int was = g_dev[dev].step_single_off ? 0 : 1;
+  if (on >= 0) g_dev[dev].step_single_off = on == 0;
+  return was;
+}
+#ifdef DIB_STEP_POLLSTATS
+extern "C" int dib_debug_poll_stats(unsigned *out4, int reset) {
+  DIB_HIP_CHECK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(dib_poll_stats), 4 * sizeof(unsigned)));
+  if (reset) { const unsigned z[4] = {0, 0, 0, 0}; DIB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(dib_poll_stats), z, sizeof(z))); }
+  return DIB_OK;
+}
+#endif
 
 namespace {
 // Per-image argument checks shared by dib_sparse_blur and the blur step's single launch.
@@ -1456,6 +1624,12 @@ int dib::blur_step_fused_launch(const void *const *psf_ptrs, int num_psfs, int n
     pp.p[i] = psf_ptrs[i];
   }
   if (int rc = prepare_device()) return rc;
+  {   // a hand-off timed out on this device before: two launches
+    int dev = 0;
+    DIB_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    if (g_dev[dev].step_single_off) return 1;
+  }
   BlurBatch tiled;
   tiled.n = 0;
   int tiles = 0;
@@ -1472,8 +1646,10 @@ int dib::blur_step_fused_launch(const void *const *psf_ptrs, int num_psfs, int n
   StepSync sy;
   sy.sync = sync; sy.rec = rec; sy.target = target; sy.n_psf = num_psfs; sy.ncx = (num_psfs + 7) & ~7; sy.tables = tables;
   sy.row = sy.ncx + quad_grid_x(tiled);
+  sy.poll_budget = g_poll_budget;
   sy.flags = (normalize & ~DIB_COMPACT_LARGE_WINDOW) ? COMPACT_NORMALIZE : 0;
   { static const int skip = getenv("DIB_STEP_DEBUG_SKIP") ? 1 : 0; if (skip) sy.flags |= COMPACT_DEBUG_SKIP; }   // diagnostics: the hand-off alone
+  if (g_step_nosignal) sy.flags |= COMPACT_DEBUG_NOSIGNAL;     // tests: a launch whose tables never arrive
   const dim3 grid(sy.row, tiled.n);
   if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_step_f16_kernel<DIB_ACC_FMA16>), grid, dim3(256), QLDS_BYTES + STEP_LDS_EXTRA, s, tiled, sy, pp);
   else hipLaunchKernelGGL((blur_step_f16_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), QLDS_BYTES + STEP_LDS_EXTRA, s, tiled, sy, pp);
@@ -1501,6 +1677,7 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   if (int rc = check_images(in_dev, out_dev, C, H, W, table_index, B, K, num_tables)) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = prepare_device()) return rc;
+  if (int rc = consume_device_status("dib_sparse_blur")) return rc;
   int i = 0;
   while (i < B) {
     BlurBatch tiled, generic;
@@ -1619,6 +1796,7 @@ extern "C" int dib_sparse_blur_normalized(const void *const *in_dev, const int *
   }
   if (int rc = check_images(in_dev, outs.data(), C.data(), H, W, table_index, B, K, num_tables)) return rc;
   if (int rc = prepare_device()) return rc;
+  if (int rc = consume_device_status("dib_sparse_blur_normalized")) return rc;
   BlurBatch tiled;
   NormArgs na;
   na.Hp = Hp; na.Wp = Wp; na.nhwc = channels_last ? 1 : 0;

@@ -33,7 +33,7 @@ static_assert(WIN_PITCH >= 64 + SEG_COLS, "window row too short for a segment");
 // is told which by its caller.
 constexpr int SEG_ROWS_L = 20, SEG_COLS_L = 63, QUAD_PITCH_L = 32 + SEG_COLS_L + 1;   // 96 elements per LDS row
 static_assert(QUAD_PITCH_L == 96, "the large window's fill writes elements lane and 64 + lane");
-constexpr int COMPACT_NORMALIZE = 1, COMPACT_NO_SEGMENTS = 4, COMPACT_LARGE_WINDOW = 8, COMPACT_DEBUG_SKIP = 0x100;   // flag bits of the compaction kernel
+constexpr int COMPACT_NORMALIZE = 1, COMPACT_NO_SEGMENTS = 4, COMPACT_LARGE_WINDOW = 8, COMPACT_DEBUG_SKIP = 0x100, COMPACT_DEBUG_NOSIGNAL = 0x200;   // flag bits of the compaction kernel
 
 __host__ __device__ inline int table_rowptr_off() { return HDR_WORDS; }
 __host__ __device__ inline int table_taps_off(int K) { return (HDR_WORDS + K + 1 + 3) & ~3; }
@@ -74,6 +74,14 @@ int compact_launch(const void *const *ptrs, int dtype, int B, int K, int normali
 int blur_step_fused_launch(const void *const *psf_ptrs, int num_psfs, int normalize, const void *const *in_dev, void *const *out_dev,
                            const int *C, const int *H, const int *W, const int *table_index, int B, int acc_mode, int *tables,
                            unsigned *sync, unsigned *rec, unsigned target, hipStream_t s);
+
+// dib_blur.hip: the device's status word (pinned host memory a kernel writes a code to instead of trapping).  Looks at the current
+// device's word WITHOUT synchronising; DIB_OK when it is clear, else the error to return (text set, word cleared; a hand-off
+// timeout also takes the blur step's single launch out of service on that device).
+int consume_device_status(const char *who);
+// number of hand-off timeouts consumed on `dev` so far: dib_step.hip clears a slot's hand-off words again when this has moved since
+// it last did (a launch that gave up may have left its counter short of the value the host expects)
+unsigned handoff_generation(int dev);
 
 #define DIB_HIP_CHECK(expr)                                                          \
   do {                                                                               \
@@ -128,6 +136,9 @@ struct StepSync {
   // Written (sc1) as soon as the PSF's segments are final, long before its offsets are: a blur workgroup that finds both tags
   // fills its first window from these words and looks at the counter only in front of its first tap loop.
   unsigned *rec;      // MAX_BATCH x STEP_REPLICAS x STEP_REC_WORDS words
+  // Polls (sc1 load + s_sleep 2, ~1 us each) a blur workgroup spends on a hand-off word before it gives up: it then writes
+  // DIB_STATUS_HANDOFF into the device's status word and ends instead of hanging or trapping (dib_blur.hip: dib_status_word).
+  unsigned poll_budget;
 };
 
 // Flat grid of a RAGGED batch on the default tiles (dib_blur.hip: blur_quad_f16_kernel<.., FLAT = true>): the 2-D grid (band

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DIB_ABI_VERSION 6 /* 6: + dib_sparse_blur_normalized (the blur with the input transform's float + normalise + zero-padded batch as its store phase); dib_blur_step runs compaction + blur as ONE launch where the shapes allow it (same results, same signature); 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad, dib_fold_bn_multi, dib_scale_rows_multi, dib_box_match / _encode_matched / _decode / _pool / _labels, dib_topk_levels, dib_det_candidates, dib_bias_act_transpose, the large LDS window; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
+#define DIB_ABI_VERSION 7 /* 7: no kernel traps any more: DIB_ETIMEOUT, dib_device_status ("Device status" below); dib_blur_step takes an optional caller workspace through dib_blur_step_ws and bounds its private buffers; 6: + dib_sparse_blur_normalized (the blur with the input transform's float + normalise + zero-padded batch as its store phase); dib_blur_step runs compaction + blur as ONE launch where the shapes allow it (same results, same signature); 5: + dib_blur_step / dib_blur_step_release (DIB_ECAPTURE, DIB_STEP_PSFS_COMPLETE), dib_normalize_resize_pad, dib_fold_bn_multi, dib_scale_rows_multi, dib_box_match / _encode_matched / _decode / _pool / _labels, dib_topk_levels, dib_det_candidates, dib_bias_act_transpose, the large LDS window; 4: + dib_bias_act_mask_nhwc, dib_relu_mask_backward, dib_add_relu_mask, dib_scatter_add_nhwc, dib_fpn_topdown_merge_nhwc, dib_stem_pool_forward / _backward, dib_post_ops, dib_jpeg_roundtrip; 2: tap-table buffers carry no scheduler trailer any more; 3: tables carry a second
                              per-tap offset array (sizes come from dib_tap_table_bytes as before)          */
 
 /* error codes */
@@ -33,6 +33,7 @@ extern "C" {
 #define DIB_EHIP (-3)    /* a HIP runtime call failed; text in dib_last_error()                */
 #define DIB_ENOT128 (-4) /* expand_targets on a PSF that is not 128 wide (utils.py:369-370)    */
 #define DIB_ECAPTURE (-5) /* dib_blur_step on a stream under graph capture without caller tables */
+#define DIB_ETIMEOUT (-6) /* an EARLIER dib_blur_step on this device gave up waiting inside its launch: see "Device status" */
 
 /* element types */
 #define DIB_F16 0
@@ -55,6 +56,23 @@ extern "C" {
 
 int dib_abi_version(void);
 const char *dib_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Device status.  No kernel of this library traps (a trap ends the process's GPU context, i.e. the training job the blur runs
+ * inside: reference engine.py:101 calls blur_image_list from a DDP rank).  Two conditions can only be seen from inside a launch:
+ *   - the single launch of dib_blur_step hands its tap tables from the grid's first workgroups to the blur's workgroups behind
+ *     them through memory.  Forward progress rests on the hardware dispatching a grid's workgroups lowest index first -- observed
+ *     on gfx950, promised by nobody.  A blur workgroup that has polled ~1 s (2^20 polls) without seeing its tables gives up;
+ *   - a tap table compacted for the other LDS window geometry (DIB_COMPACT_LARGE_WINDOW without DIB_WINDOW_LARGE or vice versa).
+ * In both cases the workgroup leaves its tile unwritten, stores a code into a word of pinned host memory the library owns (one
+ * per device) and ends.  The host never waits for that word: every dib_blur_step / dib_sparse_blur* call LOOKS at it first, and
+ * the first call after such a launch returns DIB_ETIMEOUT (hand-off) or DIB_EINVAL (geometry) with the text in
+ * dib_last_error(), launches nothing and clears the word -- the caller re-issues its batch (and knows that an earlier batch on
+ * the device came out incomplete).  After a DIB_ETIMEOUT the device stays on compaction + blur as two ordinary launches for the
+ * rest of the process.  dib_device_status(clear) looks at the current device's word without launching anything (e.g. behind a
+ * hipStreamSynchronize): DIB_OK, DIB_ETIMEOUT or DIB_EINVAL; clear != 0 also consumes it as a call above would.
+ * ------------------------------------------------------------------------------------- */
+int dib_device_status(int clear);
 
 /* ---------------------------------------------------------------------------------------
  * Tap tables.  A tap table is the device-side compacted form of one K x K PSF: header,
@@ -133,6 +151,23 @@ int dib_blur_step(const void *const *psf_ptrs, int psf_dtype, int num_psfs, int 
 int dib_blur_step_packed(const void *const *ptrs, const int *ints, int psf_dtype, int num_psfs, int K, int normalize, int B,
                          int dtype, int acc_mode, void *tables_dev, int flags, void *stream);
 int dib_blur_step_release(void);
+/* The library's own table buffers are bounded: at most 8 streams per device keep a pair; a ninth stream takes over the least
+ * recently used one's (behind one device synchronisation: that stream's last step may still be running, or the stream may be
+ * gone).  A process that cycles through short-lived streams therefore holds at most 16 buffers per device.
+ *
+ * dib_blur_step_ws: the same step on a workspace the CALLER owns -- no allocation, no library state, usable from any number of
+ * streams (one workspace per stream in flight).  workspace_dev: dib_blur_step_workspace_bytes(K, num_psfs) bytes of device
+ * memory, 256-byte aligned (hand-off words first, the tables behind them; size it for the largest batch).  ws_state: ONE host word
+ * per workspace, in / out: 0 before the workspace's first use -- that call clears the hand-off words with one
+ * hipMemsetAsync on `stream` --, updated by every call.  All launches are ordinary stream-ordered ones, so one buffer
+ * suffices: step n + 1's compaction cannot start before step n's blur has read its tables.  While `stream` is being captured
+ * into a graph the call makes two ordinary launches into the workspace's table area (a replay cannot advance ws_state).
+ * Everything else as dib_blur_step with tables_dev == NULL; results bit-identical. */
+size_t dib_blur_step_workspace_bytes(int K, int num_psfs);
+int dib_blur_step_ws(const void *const *psf_ptrs, int psf_dtype, int num_psfs, int K, int normalize,
+                     const void *const *in_dev, void *const *out_dev, const int *C, const int *H, const int *W,
+                     const int *table_index, int B, int dtype, int acc_mode, void *workspace_dev, size_t workspace_bytes,
+                     unsigned long long *ws_state, int flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused epilogue of the blur for the detector's input: `.float()` (engine.py:107-110), per-image

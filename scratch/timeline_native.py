@@ -14,16 +14,17 @@ tables = blur_ops.compact_psfs(psfs, normalize=True)
 idx = sorted(range(8), key=lambda k: -dicts[k]["psf_taps"])
 native = [torch.rand(3, h, w, generator=torch.Generator().manual_seed(31 + i)).half().to(dev) for i, (h, w) in enumerate(bench.COCO_NATIVE_SIZES)]
 l = _lib.lib(); l.dib_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+MODE = {"bitexact": _lib.DIB_ACC_BITEXACT, "fma16": _lib.DIB_ACC_FMA16}[os.environ.get("DIB_TL_MODE", "bitexact")]   # DIB_TL_MODE=fma16: the tolerance mode's timeline
 
 
 def timeline(name, imgs):
     ordered = [imgs[k] for k in idx]
-    for _ in range(50): blur_ops.sparse_blur(list(ordered), idx, tables)
+    for _ in range(50): blur_ops.sparse_blur(list(ordered), idx, tables, MODE)
     n = 16384
     for rep in range(3):
         dbg = torch.zeros(n * 8, dtype=torch.int64, device="cuda")
         l.dib_debug_set_stamp_buffer(dbg.data_ptr())
-        for _ in range(2): blur_ops.sparse_blur(list(ordered), idx, tables)
+        for _ in range(2): blur_ops.sparse_blur(list(ordered), idx, tables, MODE)
         torch.cuda.synchronize()
         l.dib_debug_set_stamp_buffer(None)
         d = dbg.cpu().numpy().reshape(n, 8)
@@ -60,6 +61,17 @@ def timeline(name, imgs):
         print("  per CU: taps-load min %d mean %.0f max %d; corr(load, finish) %.2f; corr(n_wg, finish) %.2f" % (load.min(), load.mean(), load.max(), np.corrcoef(load, fin)[0, 1], np.corrcoef(n_wg, fin)[0, 1]))
         for k in sorted(set(n_wg.tolist())):
             print("    CUs with %d workgroups: %d, finish mean %.1f us, taps-load mean %.0f" % (k, (n_wg == k).sum(), fin[n_wg == k].mean(), load[n_wg == k].mean()))
+        if name == "native" and rep == 0:      # where the dispatcher puts the 1-D grid's workgroups: list x = b & 7, entry t = b >> 3
+            for x in (0, 3):
+                sel = np.nonzero((rec & 7) == x)[0]
+                order = np.argsort(rec[sel] >> 3)
+                seq = cu[sel][order]
+                print("  list %d (XCD id %s): CU (low 8 bits) of entries 0..: %s" % (x, sorted(set(xcc[sel].tolist())), " ".join("%02x" % (c & 0xff) for c in seq[:80])))
+                same = [(seq[t] == seq[t + 32]) for t in range(len(seq) - 32)]
+                first = {}
+                for t, c in enumerate(seq): first.setdefault(int(c), []).append(t)
+                print("    entries t and t + 32 on one CU: %d of %d; entries per CU: %s" % (sum(same), len(same), sorted(len(v) for v in first.values())))
+                print("    entry lists of the first CUs:", [first[int(c)] for c in seq[:6]])
         o = np.argsort(fin)[-5:]
         for c in o: print("    late CU %x: finish %.1f, images %s" % (ucu[c], fin[c], sorted(img[cu == ucu[c]].tolist())))
 
@@ -69,4 +81,4 @@ timeline("baseline", images)
 # event-timed loop for the same launches (this build, for scale)
 for name, imgs in (("native", native), ("baseline", images)):
     ordered = [imgs[k] for k in idx]
-    print(name, "kernel_ms (event loop of 200)", sorted(bench.kernel_time_ms(lambda k: blur_ops.sparse_blur(list(ordered), idx, tables), 200) for _ in range(5))[2])
+    print(name, "kernel_ms (event loop of 200)", sorted(bench.kernel_time_ms(lambda k: blur_ops.sparse_blur(list(ordered), idx, tables, MODE), 200) for _ in range(5))[2])

@@ -22,7 +22,7 @@ def test_device_library_exports_every_declared_symbol():
     for n in names:
         assert getattr(l, n) is not None, n
     assert sorted(_lib.EXPORTS) == names          # every declared entry point has a ctypes signature, and nothing else
-    assert l.dib_abi_version() == 6
+    assert l.dib_abi_version() == 7
     assert l.dib_tap_table_bytes(128) > 0 and l.dib_tap_table_bytes(100) == 0
     assert l.dib_tap_tables_bytes(128, 8) == 8 * l.dib_tap_table_bytes(128)
     assert l.dib_nms_workspace_bytes(128) == 128 * 2 * 8
