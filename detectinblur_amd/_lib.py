@@ -17,10 +17,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIB_HIP_LIB") or os.path.join(_HERE, "libdib_hip.so")
 
 DIB_F16, DIB_F32 = 0, 1
-DIB_ACC_BITEXACT, DIB_ACC_FP32, DIB_ACC_FMA16 = 0, 1, 2
+DIB_ACC_BITEXACT, DIB_ACC_FP32, DIB_ACC_FMA16, DIB_ACC_FAST16 = 0, 1, 2, 3
 DIB_EINVAL, DIB_ESHAPE, DIB_EHIP, DIB_ENOT128, DIB_ECAPTURE, DIB_ETIMEOUT = -1, -2, -3, -4, -5, -6
 DIB_STEP_PSFS_COMPLETE, DIB_STEP_LARGE_WINDOW = 1, 2
-DIB_COMPACT_LARGE_WINDOW, DIB_WINDOW_LARGE = 8, 0x100
+DIB_COMPACT_LARGE_WINDOW, DIB_WINDOW_LARGE, DIB_COMPACT_VRUNS = 8, 0x100, 16
 
 _lib = None
 

@@ -53,9 +53,10 @@ def table_words(K):
 class TapTables:
     """Device-resident tap tables for a batch of PSFs (see include/dib.h, `Tap tables`)."""
 
-    def __init__(self, K, count, device, large=False):
+    def __init__(self, K, count, device, large=False, vruns=False):
         self.K, self.count = K, count
         self.large = bool(large)      # compacted for the large LDS window (include/dib.h: DIB_COMPACT_LARGE_WINDOW): the blur must be told
+        self.vruns = bool(vruns)      # carries the vertical-run groups DIB_ACC_FAST16 walks (DIB_COMPACT_VRUNS)
         self.words = table_words(K)
         if self.words == 0:
             raise ValueError("PSF must be 128 or 256 wide, got %d" % K)
@@ -82,6 +83,27 @@ class TapTables:
         off = i * self.words + ((8 + self.K + 1 + 3) & ~3) + 6 * self.K * self.K + (self.K * self.K + 8 if quad else 0)
         t = self.buf[off:off + n].cpu()
         return t & 0xffff, (t >> 16) & 0xffff
+
+    def vgroups(self, i):
+        """The vertical-run groups of table i as the DIB_ACC_FAST16 tap loop walks them (include/dib.h): per segment a list of
+        (lds_byte_offset, [weight bits of tap j = 0 .. n - 1]) -- tests only.  None when the table carries none."""
+        K = self.K
+        base = i * self.words
+        if not (int(self.buf[base + 5].item()) >> 17) & 1:
+            return None
+        off = base + ((((8 + K + 1 + 3) & ~3) + 6 * K * K + 2 * (K * K + 8) + 3) & ~3)
+        out = []
+        for (t0, t1, _rf, _rl, _cmn, _cmx) in self.segments(i):
+            rec = self.buf[off + 4 * t0:off + 4 * t1].cpu().view(-1, 4).tolist()
+            own = rec[0][3] & 0xffffffff          # the first record's w: its own offset | (size - 1) << 16
+            groups, g = [], 0
+            while (own >> 16) & 7 != 4:
+                n = ((own >> 16) & 7) + 1
+                x, y, z, _w = (v & 0xffffffff for v in rec[g])
+                groups.append((own & 0xffff, [y & 0xffff, y >> 16, z & 0xffff, z >> 16][:n]))
+                own, g = x, g + 1
+            out.append(groups)
+        return out
 
     def taps(self, i):
         """(rows, cols, weight_bits) of table i as CPU tensors -- tests only."""
@@ -118,12 +140,14 @@ def large_window_pays(blur_dicts, n_images):
 LARGE_WINDOW_MAX_IMAGES = 2
 
 
-def compact_psfs(psfs, normalize, large_window=False):
+def compact_psfs(psfs, normalize, large_window=False, vruns=False):
     """psfs: list of K x K tensors (same K, same dtype) or one [B,K,K] tensor -> TapTables.
     A list is passed as device pointers (no stacking copy).  `large_window`: segment the taps for the large LDS window of
-    the default fp16 tiles (TapTables.large; sparse_blur then runs the large-window kernel)."""
+    the default fp16 tiles (TapTables.large; sparse_blur then runs the large-window kernel).  `vruns`: also write the
+    vertical-run groups that DIB_ACC_FAST16 walks (fp16 PSFs on the 128 canvas, standard window)."""
     l = _lib.lib()
-    flags = int(bool(normalize)) | (_lib.DIB_COMPACT_LARGE_WINDOW if large_window else 0)
+    vruns = bool(vruns) and not large_window
+    flags = int(bool(normalize)) | (_lib.DIB_COMPACT_LARGE_WINDOW if large_window else 0) | (_lib.DIB_COMPACT_VRUNS if vruns else 0)
     if isinstance(psfs, (list, tuple)):
         first = psfs[0]
         _require_cuda(first, "PSF")
@@ -144,7 +168,7 @@ def compact_psfs(psfs, normalize, large_window=False):
                 a = p.data_ptr()
             keep.append(p)
             ptrs.append(a)
-        tabs = TapTables(K, len(keep), first.device, large_window)
+        tabs = TapTables(K, len(keep), first.device, large_window, vruns and K == 128 and dt == torch.float16)
         tabs._pin = keep   # alive until the tables die
         _lib.check(l.dib_psf_compact_list(_lib.ptr_array(ptrs), _DT[dt], len(keep), K, flags,
                                           tabs.buf.data_ptr(), _stream(first.device)))
@@ -157,7 +181,7 @@ def compact_psfs(psfs, normalize, large_window=False):
     if stack.dtype not in _DT:
         raise TypeError("PSF dtype %s not supported (float16 / float32)" % stack.dtype)
     B, K = stack.shape[0], stack.shape[1]
-    tabs = TapTables(K, B, stack.device, large_window)
+    tabs = TapTables(K, B, stack.device, large_window, vruns and K == 128 and stack.dtype == torch.float16)
     _lib.check(l.dib_psf_compact(stack.data_ptr(), _DT[stack.dtype], B, K, flags,
                                  tabs.buf.data_ptr(), _stream()))
     return tabs
@@ -228,6 +252,9 @@ def sparse_blur(images, table_index, tables, acc_mode=_lib.DIB_ACC_BITEXACT):
         return list(images)
     outs, ins_p, outs_p, Cs, Hs, Ws, dt, dev, _keep = d
     _await(tables)
+    if acc_mode == _lib.DIB_ACC_FAST16 and not tables.vruns:
+        raise ValueError("DIB_ACC_FAST16 walks the tables' vertical-run groups: compact with compact_psfs(..., vruns=True) "
+                         "(fp16 PSFs on the 128 canvas, standard window); without them the library would run DIB_ACC_FMA16's loop")
     if tables.large:
         acc_mode |= _lib.DIB_WINDOW_LARGE          # the tables hold the large window's segments and offsets
     args = (_lib.ptr_array(ins_p), _lib.ptr_array(outs_p), _lib.int_array(Cs), _lib.int_array(Hs), _lib.int_array(Ws),
@@ -400,7 +427,7 @@ def side_stream(device):
     return _side_streams[idx]
 
 
-def compact_psfs_ahead(psfs, normalize, after_current=True, large_window=False):
+def compact_psfs_ahead(psfs, normalize, after_current=True, large_window=False, vruns=False):
     """compact_psfs on the device's side stream.  `after_current`: the side stream first waits for the work already
     queued on the current stream (needed when that work PRODUCES the PSFs, e.g. their host-to-device copy was issued
     on it); pass False when the PSFs are known to be complete (bench.py's resident PSFs), so that the compaction may
@@ -412,7 +439,7 @@ def compact_psfs_ahead(psfs, normalize, after_current=True, large_window=False):
     if after_current:
         side.wait_stream(main)
     with torch.cuda.stream(side):
-        tabs = compact_psfs(psfs, normalize, large_window)
+        tabs = compact_psfs(psfs, normalize, large_window, vruns)
         tabs.ready = torch.cuda.Event()
         tabs.ready.record(side)
     # the PSFs were allocated on the main stream and are read on the side stream: tell the caching allocator, or a

@@ -297,9 +297,12 @@ def get_coco_api_from_dataset(dataset):
     return convert_to_coco_api(dataset)
 
 
-def get_coco(root, image_set, transforms, mode="instances", synthetic=None):
+def get_coco(root, image_set, transforms, mode="instances", synthetic=None, with_masks=True):
     """reference coco_utils.py:243-271.  Returns `(dataset, num_classes)` (the reference's train.get_dataset
-    adds the 91; folded in here).  With `synthetic` (a dict of SyntheticCocoDetection kwargs) `root` is ignored."""
+    adds the 91; folded in here).  With `synthetic` (a dict of SyntheticCocoDetection kwargs) `root` is ignored.
+    `with_masks=False` (what the detection drivers pass unless `--with_masks` is given): the targets carry no `masks` -- the
+    reference rasterises every object's full-resolution mask in the loader and resizes it with the image every step for a
+    Faster R-CNN that never reads it; the default here keeps the reference's target dict."""
     if synthetic is not None:
         return SyntheticCocoDetection(transforms=transforms, **synthetic), 91
     if root is None:
@@ -308,7 +311,7 @@ def get_coco(root, image_set, transforms, mode="instances", synthetic=None):
     anno_file_template = "{}_{}2017.json"
     PATHS = {"train": ("train2017", os.path.join("annotations", anno_file_template.format(mode, "train"))),
              "val": ("val2017", os.path.join("annotations", anno_file_template.format(mode, "val")))}
-    t = [ConvertCocoPolysToMask()]
+    t = [ConvertCocoPolysToMask(with_masks=with_masks)]
     if transforms is not None:
         t.append(transforms)
     img_folder, ann_file = PATHS[image_set]

@@ -662,6 +662,95 @@ __device__ __forceinline__ void tap_loop_quad_fp32(float (&acc)[16], unsigned lo
 #undef DIB_RF_ASM
 }
 
+// ---- DIB_ACC_FAST16: the tap loop over VERTICAL-RUN GROUPS (dib_common.h: vgroups) -----------------------------------------------
+// The tolerance mode may accumulate a window's taps in any order, so they arrive regrouped: n <= 4 taps of one PSF column in
+// consecutive PSF rows.  A lane's four output rows need window rows j .. j + 3 for tap j of the group, i.e. n + 3 rows for the
+// whole group instead of 4 n: 5 / 6 / 7 ds_read_b64 for 2 / 3 / 4 taps.  That is what this mode was short of: with one v_pk_fma_f16
+// per register and tap the vector ALU (8 x 4 cycles per wave-tap) and the LDS (4 x 512 B per wave-tap at 256 B per clock and CU, four
+// SIMDs reading) need the SAME 32 cycles per tap, and DIB_ACC_FMA16's loop ran at 56 (profiles/r2_blur_tap_slope.txt).
+// A segment's groups come sorted by size, fours first, so the loop is four straight-line bodies -- no size tests inside a body --
+// and changes body at most three times per segment: per group one wait, one scalar load, one LDS address, n + 3 reads, 8 n
+// multiply-adds and five scalar instructions, where the plain loop spends five scalar instructions per TAP (this mode is as
+// sensitive to scalar instructions as to vector ones: 0.6 us of launch time per million of either).
+//   buffers  X = v[32:45], Y = v[46:59]: rows 0 .. 6 of a group (row k in v[base + 2 k : base + 2 k + 1]), v60 the LDS address
+//   records  S0 = s[36:39] with X, S1 = s[40:43] with Y: the record of the group being multiplied also names the NEXT group's
+//            offset and size (x), so its rows can be requested before its own record has arrived
+//   a step   wait (this group's rows, this group's record) | request the next group's record into the other set | request the
+//            next group's rows (n + 3 of them: the next group is no larger) | multiply-add this group | same size next? go on
+// Taps of a group run from its lowest PSF row to its highest (j = n - 1 .. 0): the order the oracle restates (tests/test_fast16_gpu.py).
+// Operands: %0-%7 accumulators, %8 byte offset of the next record to request, %9 the section's base, %10 lane base.
+#define VR_LO "op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+#define VR_HI "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+#define VR_FMA(i, W, SEL, B, k) "v_pk_fma_f16 %" #i ", " W ", v[" #B "+" #k "], %" #i " " SEL "\n\t"
+// tap j of the group in buffer B: window rows j .. j + 3 -> accumulators (2 i, 2 i + 1) of output row i
+#define VR_TAP(B, j, W, SEL) VR_FMA(0, W, SEL, B, 2*j) VR_FMA(1, W, SEL, B, 2*j+1) VR_FMA(2, W, SEL, B, 2*j+2) VR_FMA(3, W, SEL, B, 2*j+3) \
+  VR_FMA(4, W, SEL, B, 2*j+4) VR_FMA(5, W, SEL, B, 2*j+5) VR_FMA(6, W, SEL, B, 2*j+6) VR_FMA(7, W, SEL, B, 2*j+7)
+#define VR_TAPH(B, j, W, SEL) VR_FMA(0, W, SEL, B, 2*j) VR_FMA(2, W, SEL, B, 2*j+2) VR_FMA(4, W, SEL, B, 2*j+4) VR_FMA(6, W, SEL, B, 2*j+6)
+#define VR_RD(B, k, off) "ds_read_b64 v[" #B "+2*" #k ":" #B "+2*" #k "+1], v60 offset:" #off "\n\t"
+#define VR_RDH(B, k, off) "ds_read_b32 v[" #B "+2*" #k "], v60 offset:" #off "\n\t"
+// the rows of a group of N taps at LDS offset OFF (the low 16 bits of a scalar) into buffer B
+#define VR_READS4(RD, B, OFF) "v_mad_u32_u16 v60, " OFF ", 1, %10\n\t" RD(B, 0, 0) RD(B, 1, 448) RD(B, 2, 896) RD(B, 3, 1344) RD(B, 4, 1792) RD(B, 5, 2240) RD(B, 6, 2688)
+#define VR_READS3(RD, B, OFF) "v_mad_u32_u16 v60, " OFF ", 1, %10\n\t" RD(B, 0, 0) RD(B, 1, 448) RD(B, 2, 896) RD(B, 3, 1344) RD(B, 4, 1792) RD(B, 5, 2240)
+#define VR_READS2(RD, B, OFF) "v_mad_u32_u16 v60, " OFF ", 1, %10\n\t" RD(B, 0, 0) RD(B, 1, 448) RD(B, 2, 896) RD(B, 3, 1344) RD(B, 4, 1792)
+#define VR_READS1(RD, B, OFF) "v_mad_u32_u16 v60, " OFF ", 1, %10\n\t" RD(B, 0, 0) RD(B, 1, 448) RD(B, 2, 896) RD(B, 3, 1344)
+// the 8 N multiply-adds of the group in buffer B, weights w0 | w1 << 16 in W01, w2 | w3 << 16 in W23
+#define VR_ARITH4(TAP, B, W01, W23) TAP(B, 3, W23, VR_HI) TAP(B, 2, W23, VR_LO) TAP(B, 1, W01, VR_HI) TAP(B, 0, W01, VR_LO)
+#define VR_ARITH3(TAP, B, W01, W23) TAP(B, 2, W23, VR_LO) TAP(B, 1, W01, VR_HI) TAP(B, 0, W01, VR_LO)
+#define VR_ARITH2(TAP, B, W01, W23) TAP(B, 1, W01, VR_HI) TAP(B, 0, W01, VR_LO)
+#define VR_ARITH1(TAP, B, W01, W23) TAP(B, 0, W01, VR_LO)
+// one step of the body for groups of N taps (NM1 = N - 1 as a string): the group in buffer BC (record C0 .. C2) is multiplied while
+// the next group's rows go to BN and its record to the OTHER register set; P / Q: this step's and the other step's parity letter
+#define VR_STEP(N, NM1, RD, TAP, BC, BN, C0, C1, C2, OTHER, P, Q)                                            \
+  "Lvr_c" #N P "%=:\n\t"                                                                                    \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                \
+  "s_load_dwordx4 " OTHER ", %9, %8\n\ts_add_u32 %8, %8, 16\n\t"                                            \
+  VR_READS##N(RD, BN, C0)                                                                                   \
+  "s_bfe_u32 s46, " C0 ", 0x30010\n\t"                                                                      \
+  VR_ARITH##N(TAP, BC, C1, C2)                                                                              \
+  "s_cmp_eq_u32 s46, " NM1 "\n\ts_cbranch_scc1 Lvr_c" #N Q "%=\n\t"                                         \
+  "s_branch Lvr_d" Q "%=\n\t"
+#define VR_BODY(N, NM1, RD, TAP)                                                                             \
+  VR_STEP(N, NM1, RD, TAP, 32, 46, "s36", "s37", "s38", "s[40:43]", "x", "y")                               \
+  VR_STEP(N, NM1, RD, TAP, 46, 32, "s40", "s41", "s42", "s[36:39]", "y", "x")
+// which body runs the group whose size code is in s46 (4: the segment is done), by the buffer its rows are in
+#define VR_DISPATCH(P)                                                                                       \
+  "Lvr_d" P "%=:\n\t"                                                                                       \
+  "s_cmp_eq_u32 s46, 4\n\ts_cbranch_scc1 Lvr_done%=\n\t"                                                    \
+  "s_cmp_eq_u32 s46, 3\n\ts_cbranch_scc1 Lvr_c4" P "%=\n\t"                                                 \
+  "s_cmp_eq_u32 s46, 2\n\ts_cbranch_scc1 Lvr_c3" P "%=\n\t"                                                 \
+  "s_cmp_eq_u32 s46, 1\n\ts_cbranch_scc1 Lvr_c2" P "%=\n\t"                                                 \
+  "s_branch Lvr_c1" P "%=\n\t"
+template <bool HALF>
+__device__ __forceinline__ void tap_loop_quad_vrun(h2 (&acc)[8], unsigned long long vgroups, int g0, unsigned lane_addr) {
+  unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(g0 * 16);
+  unsigned a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
+#define DIB_VR_ASM(RD, TAP) \
+  asm volatile( \
+      /* the segment's first record: its own offset and size sit in w; its rows are requested for the largest size (rows past a \
+         smaller group's are read and not used: the window's own rows, or zeros past the workgroup's LDS) */ \
+      "s_load_dwordx4 s[36:39], %9, %8\n\ts_add_u32 %8, %8, 16\n\t" \
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+      "s_bfe_u32 s46, s39, 0x30010\n\t" \
+      VR_READS4(RD, 32, "s39") \
+      "s_branch Lvr_dx%=\n\t" \
+      VR_BODY(4, "3", RD, TAP) VR_BODY(3, "2", RD, TAP) VR_BODY(2, "1", RD, TAP) VR_BODY(1, "0", RD, TAP) \
+      VR_DISPATCH("x") VR_DISPATCH("y") \
+      "Lvr_done%=:\n\t" \
+      "s_waitcnt lgkmcnt(0)" \
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+s"(toff) \
+      : "s"(vgroups), "v"(lane_addr) \
+      : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", \
+        "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s46", \
+        "scc", "memory")
+  if constexpr (HALF) { DIB_VR_ASM(VR_RDH, VR_TAPH); }
+  else { DIB_VR_ASM(VR_RD, VR_TAP); }
+#undef DIB_VR_ASM
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
+}
+
 // STEP (the blur step's single launch, blur_step_f16_kernel): with `early` set the segment count and the first segment come
 // from the caller (the compaction's early record: the table itself must not be touched yet) and `wait_tables()` is called
 // once, between the first window's barrier and the first tap loop -- the first reader of the table's offsets.
@@ -693,6 +782,7 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   // out because hipcc turns these into vector loads + v_readfirstlane once an asm statement precedes them.
   const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
   int nsegs;
+  int use_vruns = 0;
   uint4 seg;
   if (STEP && early) {
     nsegs = nsegs0 | 1 << 30;       // bit 30: "wait for the tables in front of the first tap loop" (no register of its own)
@@ -708,7 +798,13 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
     // holds offsets for another LDS pitch: garbage pixels, silently.  The workgroup leaves its tile unwritten instead and says so in
     // the device's status word (the next call on the device returns DIB_EINVAL; blur_ops.sparse_blur checks on the host first).
     // (the step's single launch compacts its own tables, for the standard window: nothing to check there)
-    if constexpr (!STEP) { if (((unsigned)(hd >> 32) >> 16) != (L ? 1u : 0u)) report_and_exit(DIB_STATUS_GEOMETRY, (unsigned)(hd >> 32)); }
+    if constexpr (!STEP) {
+      const unsigned kw = (unsigned)(hd >> 32) >> 16;      // bit 0: large window, bit 1: the vertical-run groups are there
+      if ((kw & 1u) != (L ? 1u : 0u)) report_and_exit(DIB_STATUS_GEOMETRY, (unsigned)(hd >> 32));
+      // DIB_ACC_FAST16 on a table without groups (compacted without DIB_COMPACT_VRUNS, or a PSF beyond the compaction's LDS
+      // stage: > 4,096 taps): the plain fused loop, taps in row-major order -- the same arithmetic, DIB_ACC_FMA16's result
+      if constexpr (ACC == DIB_ACC_FAST16) use_vruns = (int)(kw >> 1) & 1;
+    }
   }
   static_assert(HDR_NSEGS == 7 && HDR_K == 5 && HDR_WORDS == 8, "header words 4..7 in the asm above");
   const unsigned long long la = (unsigned long long)(tab + table_ltaps_q_off(K));
@@ -737,6 +833,9 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
 #ifdef DIB_TIMELINE
   if (!L && !STEP && wave == 0 && fresh_lane() == 0)
     *(__attribute__((address_space(3))) unsigned long long *)(size_t)(lds0 + QGeom<false>::BYTES + 32) = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef DIB_FILL_PRIO
+  __builtin_amdgcn_s_setprio(DIB_FILL_PRIO);      // experiment (docs/experiments.md): prologue + window fill ahead of the older waves' tap loops
 #endif
   for (int sg = 0; sg < (STEP ? (nsegs & 0xffffff) : nsegs); ++sg) {
     if (sg > 0) seg = segs[sg];
@@ -791,7 +890,11 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
         if (part * GP + g >= GQ) continue;
         const int so = __builtin_amdgcn_readfirstlane(soff[part * GP + g]);
 #pragma unroll
+#ifdef DIB_EXP_NOFILL      /* experiment: what the launch costs without its window loads (garbage pixels) */
+        for (int k = 0; k < NK; ++k) v[g][k] = (short)(so + k);
+#else
         for (int k = 0; k < NK; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
+#endif
       }
 #ifdef DIB_TIMELINE
       if (!L && !STEP && sg == 0 && part == 0 && wave == 0 && fresh_lane() == 0)
@@ -855,11 +958,28 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       *(__attribute__((address_space(3))) unsigned long long *)(size_t)(lds0 + QGeom<false>::BYTES + 16) = __builtin_amdgcn_s_memrealtime();
 #endif
     if constexpr (STEP) { if (sg == 0 && (nsegs >> 30)) wait_tables(); }
+#ifdef DIB_FILL_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const int tl = fresh_lane();
     const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
     if constexpr (ACC == DIB_ACC_FP32) {
       if (W - x0f() <= 64) tap_loop_quad_fp32<true, L>(acc32, ltaps, w.t0, w.n, lane_addr);
       else tap_loop_quad_fp32<false, L>(acc32, ltaps, w.t0, w.n, lane_addr);
+#ifdef DIB_EXP_NOTAPS      /* experiment: the launch without its tap loops (fill + store only) */
+    } else if constexpr (ACC == DIB_ACC_FAST16 || ACC == DIB_ACC_FMA16) {
+      acc[0] = __builtin_bit_cast(h2, *(__attribute__((address_space(3))) unsigned *)(size_t)lane_addr);
+#endif
+    } else if constexpr (ACC == DIB_ACC_FAST16) {
+      // the segment's vertical-run groups: records from index t0 on (dib_common.h: vgroups)
+      const unsigned long long va = (unsigned long long)(tab + table_vgroups_off(K));
+      const unsigned long long vg = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(va >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)va);
+      if (!use_vruns) {
+        if (W - x0f() <= 64) tap_loop_quad<true, true, L>(acc, ltaps, w.t0, w.n, lane_addr);
+        else tap_loop_quad<true, false, L>(acc, ltaps, w.t0, w.n, lane_addr);
+      } else if (W - x0f() <= 64) tap_loop_quad_vrun<true>(acc, vg, w.t0, lane_addr);
+      else tap_loop_quad_vrun<false>(acc, vg, w.t0, lane_addr);
     } else {
       if (W - x0f() <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true, L>(acc, ltaps, w.t0, w.n, lane_addr);
       else tap_loop_quad<ACC == DIB_ACC_FMA16, false, L>(acc, ltaps, w.t0, w.n, lane_addr);
@@ -901,6 +1021,10 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       }
     }
   } else {
+#ifdef DIB_EXP_NOSTORE     /* experiment: the launch without its stores (one lane keeps the accumulators alive) */
+    if (acc[0].x == (_Float16)12345.f && acc[7].y == (_Float16)-777.f) *(volatile int *)d.out = 1;
+    return;
+#endif
     // STEP: the plane offset ch * H * W * 2 is formed again here (from an opaque copy of ch) instead of staying alive from the
     // input descriptor's across the segment loop: two scalar registers the step kernel does not have (it spilled them).
     int chs = ch;
@@ -959,7 +1083,12 @@ constexpr int TL_WORD = QLDS_BYTES / 4;
 // proportion (8 waves per SIMD: ~10 cycles per instruction and wave, times 3.2 rounds of workgroups).
 // FLAT (ragged batches, dib_common.h: FlatBands): a 1-D grid of exactly the working workgroups; the image comes from one more
 // scalar load (the XCD list's 16 entry offsets) in front of the descriptor's.
-template <int ACC, int KC, bool FLAT = false>
+// TPW (tiles per workgroup; > 1 on the 2-D grid of DIB_ACC_FAST16 only): a workgroup computes TPW consecutive tiles of its band one
+// after the other.  That mode is bound by what a workgroup's LIFE costs -- eight slots per CU, a slot's phases (dispatch gap,
+// prologue, window fill, taps, store) one after the other: the launch time is their SUM (scratch ablations: skeleton 10.9 + loads
+// 9.4 + taps 10.8 + stores 4.0 us against 31.5 us measured) -- and the second tile pays neither the ~0.9 us between a workgroup's
+// end and the next one's start on its slot nor the descriptor's scalar round trip.
+template <int ACC, int KC, bool FLAT = false, int TPW = 1>
 __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, FlatBands fb) {
   constexpr int K = KC;
   extern __shared__ unsigned nlds[];
@@ -967,7 +1096,7 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
   if constexpr (FLAT) {
     typedef int i16v __attribute__((ext_vector_type(16)));
     const i16v bb = *reinterpret_cast<const i16v *>(fb.begin[blockIdx.x & 7]);
-    const int len = bb[15] & 0x3fffffff;      // bit 30: walk every other stride backwards (off only in A/B runs: dib_debug_set_flat_snake)
+    const int len = bb[15];
     if (entry >= len) return;
     // Boustrophedon over the dispatcher's round robin.  A ragged batch is ONE round of workgroups, all resident at once, and the
     // hardware deals a list's workgroups to its XCD's 32 CUs in turn: CU j runs workgroups j, j + 32, j + 64, ... of the list
@@ -978,7 +1107,7 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
     // done, meet the lightest entries of the stride before): 259.  Which TILE a workgroup computes is all that changes.
     {
       const int row = entry >> 5, full = len >> 5;
-      if ((bb[15] >> 30) && row < full && ((full - 1 - row) & 1) == 0) entry ^= 31;
+      if (row < full && row < 32 && ((fb.rev_mask >> row) & 1u)) entry ^= 31;
     }
     int start = bb[0];
     img_i = 0;
@@ -1004,6 +1133,19 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
                "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab));
   const int per_ch = d.tiles_x * d.tiles_y;
   int local;
+  if constexpr (TPW > 1) {
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#pragma unroll 1
+    for (int k = 0; k < TPW; ++k) {
+      if (!band_entry(d.C * per_ch, blockIdx.x & 7, entry * TPW + k, local)) break;
+      const int ch = magic_div(local, d.inv_per_ch);
+      local -= ch * per_ch;
+      const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
+      if (k > 0) __syncthreads();          // every wave is done with the previous tile's window
+      blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, lds_addr(nlds), wv);
+    }
+    return;
+  }
   if (!band_entry(d.C * per_ch, blockIdx.x & 7, entry, local)) return;
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
@@ -1119,7 +1261,7 @@ struct StepWait {
         "s_endpgm\n\t"
         "Ldibw_done%=:\n\t"
 #ifdef DIB_STEP_POLLSTATS
-        "s_cmp_eq_u32 s41, 0\n\t"
+        "s_cmp_lt_u32 s41, 33\n\t"                /* only the long waits are recorded: thousands of same-address atomics per launch cost milliseconds */
         "s_cbranch_scc1 Ldibw_nostat%=\n\t"
         "s_getpc_b64 s[36:37]\n\t"
         "s_add_u32 s36, s36, dib_poll_stats@rel32@lo+4\n\t"
@@ -1212,7 +1354,10 @@ __global__ __launch_bounds__(256, 8) void blur_step_f16_kernel(BlurBatch batch, 
       __builtin_amdgcn_s_sleep(2);
     }
 #ifdef DIB_STEP_POLLSTATS
-    if (pspins && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicMax(&dib_poll_stats[0], pspins);
+    // (only a new maximum is recorded: thousands of same-address atomics per launch cost milliseconds)
+    if (pspins > 32 && wave == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0 &&
+        pspins > __hip_atomic_load(&dib_poll_stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(&dib_poll_stats[0], pspins);
 #endif
     // what StepWait needs, into the 16 bytes of LDS behind the window (every wave's lane 0 writes the same three words)
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
@@ -1408,6 +1553,12 @@ extern "C" void dib_debug_set_flat_grid(int on) { g_flat_grid = on ? 1 : 0; }
 // ... and on it, every other stride of 32 workgroups of an XCD's list walked backwards (default; 0 in A/B runs)
 static int g_flat_snake = !(getenv("DIB_FLAT_SNAKE") && getenv("DIB_FLAT_SNAKE")[0] == '0');
 extern "C" void dib_debug_set_flat_snake(int on) { g_flat_snake = on ? 1 : 0; }
+// DIB_ACC_FAST16 on the 2-D grid: tiles a workgroup computes one after the other (1 .. 4; DIB_FAST16_TPW)
+static int tpw_from_env() { const char *e = getenv("DIB_FAST16_TPW"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 4 ? v : 1; }
+static int g_fast16_tpw = tpw_from_env();
+extern "C" void dib_debug_set_fast16_tpw(int n) { g_fast16_tpw = n >= 1 && n <= 4 ? n : 1; }
+static int g_flat_mask = -1;      // experiments: an explicit stride mask
+extern "C" void dib_debug_set_flat_mask(int mask) { g_flat_mask = mask; }
 
 namespace {
 // Per-device launch state: the dynamic-LDS opt-in is a per-device function attribute.  Guarded by a mutex: entry
@@ -1447,6 +1598,11 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 128, true>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128, true>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, true>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 2>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 3>), QLDS_BYTES + TL_EXTRA));
+    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 4>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_norm_kernel<DIB_ACC_BITEXACT, 128>), QLDS_BYTES));
@@ -1489,7 +1645,7 @@ static int consume_status_locked(DeviceState &st, int dev, const char *who) {
   if (code == DIB_STATUS_GEOMETRY) {
     set_error("%s: an earlier launch on device %d was handed a tap table compacted for the %s LDS window (DIB_COMPACT_LARGE_WINDOW "
               "and DIB_WINDOW_LARGE / DIB_STEP_LARGE_WINDOW must agree): its images were left unwritten", who, dev,
-              (detail >> 16) ? "large" : "standard");
+              ((detail >> 16) & 1u) ? "large" : "standard");
     return DIB_EINVAL;
   }
   set_error("%s: unknown device status %u on device %d", who, code, dev);
@@ -1672,8 +1828,12 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     set_error("dib_sparse_blur: DIB_WINDOW_LARGE serves fp16 images in DIB_ACC_BITEXACT / DIB_ACC_FMA16 on the default tile shape only");
     return DIB_EINVAL;
   }
-  if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FP32 && acc_mode != DIB_ACC_FMA16) { set_error("dib_sparse_blur: unknown accumulation mode %d", acc_mode); return DIB_EINVAL; }
-  if (acc_mode != DIB_ACC_BITEXACT && dtype != DIB_F16) { set_error("dib_sparse_blur: DIB_ACC_FP32 / DIB_ACC_FMA16 apply to fp16 images only (fp32 images already accumulate in fp32)"); return DIB_EINVAL; }
+  if (acc_mode != DIB_ACC_BITEXACT && acc_mode != DIB_ACC_FP32 && acc_mode != DIB_ACC_FMA16 && acc_mode != DIB_ACC_FAST16) { set_error("dib_sparse_blur: unknown accumulation mode %d", acc_mode); return DIB_EINVAL; }
+  if (acc_mode != DIB_ACC_BITEXACT && dtype != DIB_F16) { set_error("dib_sparse_blur: DIB_ACC_FP32 / DIB_ACC_FMA16 / DIB_ACC_FAST16 apply to fp16 images only (fp32 images already accumulate in fp32)"); return DIB_EINVAL; }
+  if (acc_mode == DIB_ACC_FAST16 && (K != 128 || large || g_shape != 0)) {
+    set_error("dib_sparse_blur: DIB_ACC_FAST16 serves K = 128 on the default tiles and the standard window (tables compacted with DIB_COMPACT_VRUNS)");
+    return DIB_EINVAL;
+  }
   if (int rc = check_images(in_dev, out_dev, C, H, W, table_index, B, K, num_tables)) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (int rc = prepare_device()) return rc;
@@ -1728,7 +1888,7 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
       // ragged batch on the default tiles: a 1-D grid of exactly the working workgroups (FlatBands, dib_common.h)
       FlatBands fb = {};
       bool flat = false;
-      if (quad && !large && K == 128 && g_flat_grid && tiled.n > 1 && tiled.n <= FLAT_MAX && acc_mode != DIB_ACC_FP32) {
+      if (quad && !large && K == 128 && g_flat_grid && tiled.n > 1 && tiled.n <= FLAT_MAX && acc_mode != DIB_ACC_FP32) {    // (FAST16 included)
         for (int k = 1; k < tiled.n && !flat; ++k)
           flat = tiled.tile_begin[k + 1] - tiled.tile_begin[k] != tiled.tile_begin[1] - tiled.tile_begin[0];
         if (flat) {
@@ -1746,6 +1906,11 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
             longest = at > longest ? at : longest;
           }
           grid = dim3(8 * longest, 1);
+          // strides walked backwards: every other one, the last full one always (the kernel's comment); A/B runs set the mask
+          const int full = (longest >> 5) > 32 ? 32 : (longest >> 5);
+          unsigned snake = 0;
+          for (int r = full - 1; r >= 0; r -= 2) snake |= 1u << r;
+          fb.rev_mask = g_flat_mask >= 0 ? (unsigned)g_flat_mask : (g_flat_snake ? snake : 0u);
         }
       }
 #define DIB_LAUNCH_QUAD(ACCM)                                                                                             \
@@ -1756,7 +1921,15 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     else if (K == 128) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb); \
     else hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 256>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);          \
   } while (0)
-      if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_QUAD(DIB_ACC_FMA16);
+      if (quad && acc_mode == DIB_ACC_FAST16) {
+        const int tpw = g_fast16_tpw;
+        const dim3 gt(((gx / 8 + tpw - 1) / tpw) * 8, tiled.n);      // TPW consecutive entries of a band per workgroup
+        if (flat) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, true>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
+        else if (tpw == 2) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 2>), gt, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
+        else if (tpw == 3) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 3>), gt, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
+        else if (tpw == 4) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 4>), gt, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
+        else hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
+      } else if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_QUAD(DIB_ACC_FMA16);
       else if (quad && acc_mode == DIB_ACC_FP32 && K == 128) hipLaunchKernelGGL((blur_quad_f32acc_kernel<128>), grid, dim3(256), QLDS_BYTES, s, tiled);
       else if (quad && acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_quad_f32acc_kernel<256>), grid, dim3(256), QLDS_BYTES, s, tiled);
       else if (quad) DIB_LAUNCH_QUAD(DIB_ACC_BITEXACT);

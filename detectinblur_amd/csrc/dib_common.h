@@ -33,14 +33,29 @@ static_assert(WIN_PITCH >= 64 + SEG_COLS, "window row too short for a segment");
 // is told which by its caller.
 constexpr int SEG_ROWS_L = 20, SEG_COLS_L = 63, QUAD_PITCH_L = 32 + SEG_COLS_L + 1;   // 96 elements per LDS row
 static_assert(QUAD_PITCH_L == 96, "the large window's fill writes elements lane and 64 + lane");
-constexpr int COMPACT_NORMALIZE = 1, COMPACT_NO_SEGMENTS = 4, COMPACT_LARGE_WINDOW = 8, COMPACT_DEBUG_SKIP = 0x100, COMPACT_DEBUG_NOSIGNAL = 0x200;   // flag bits of the compaction kernel
+constexpr int COMPACT_NORMALIZE = 1, COMPACT_NO_SEGMENTS = 4, COMPACT_LARGE_WINDOW = 8, COMPACT_VRUNS = 16, COMPACT_DEBUG_SKIP = 0x100, COMPACT_DEBUG_NOSIGNAL = 0x200;   // flag bits of the compaction kernel
+// Vertical-run groups (DIB_COMPACT_VRUNS -> DIB_ACC_FAST16, the tolerance mode that may reorder taps): inside a segment, taps of one
+// PSF column in consecutive PSF rows form a run; a run is cut into groups of at most VRUN_MAX taps.  The n taps of a group share
+// n + 3 window rows per lane (the lane's four output rows slide down the column) instead of 4 n: half the LDS reads of the tap
+// loop.  The groups of the segment whose taps are [t0, t1) occupy records t0, t0 + 1, ... of the table's `vgroups` section, one
+// uint4 each:
+//   x = LDS byte offset of the NEXT group's first window row and column (low 16) | (its tap count - 1) << 16; 4 << 16 behind the last
+//   y = w0 | w1 << 16,  z = w2 | w3 << 16     fp16 weights; tap j of the group reads window rows j .. j + 3 from the group's
+//                                             offset: w0 belongs to the HIGHEST PSF row of the group
+//   w = in the segment's FIRST record: its own offset | (its tap count - 1) << 16 (the form of x)
+// so that a tap loop needs the record of group g alone to run group g and to fetch group g + 1's pixels.  A segment's groups are
+// stored sorted by size, fours first: the loop runs one straight-line body per size and changes body at most three times.
+// tab[HDR_K] bit 17 says that the section is valid (fp16 PSF, standard window, every segment's taps staged in LDS).
+constexpr int VRUN_MAX = 4;
+constexpr unsigned HDR_K_VRUNS = 1u << 17;
 
 __host__ __device__ inline int table_rowptr_off() { return HDR_WORDS; }
 __host__ __device__ inline int table_taps_off(int K) { return (HDR_WORDS + K + 1 + 3) & ~3; }
 __host__ __device__ inline int table_segs_off(int K) { return table_taps_off(K) + 2 * K * K; }
 __host__ __device__ inline int table_ltaps_off(int K) { return table_segs_off(K) + 4 * K * K; }
 __host__ __device__ inline int table_ltaps_q_off(int K) { return table_ltaps_off(K) + K * K + 8; }
-__host__ __device__ inline int table_words(int K) { return table_ltaps_q_off(K) + K * K + 8; }
+__host__ __device__ inline int table_vgroups_off(int K) { return (table_ltaps_q_off(K) + K * K + 8 + 3) & ~3; }   // uint4 records: 16-byte aligned
+__host__ __device__ inline int table_words(int K) { return table_vgroups_off(K) + 4 * K * K + 16; }
 
 // ---- padding modes of manual_blur (models/blur_functions.py:28-31, :55-58) ---------------
 enum PadMode { PAD_REFLECT = 0, PAD_ZERO = 1, PAD_REPLICATE = 2 };
@@ -148,7 +163,7 @@ struct StepSync {
 // x of image 0, then band x of image 1, ...: begin[x][k] = entry at which image k starts (INT_MAX for k >= n), begin[x][15] =
 // the list's length.  One 64-byte scalar load per workgroup; at most FLAT_MAX images per launch.
 constexpr int FLAT_MAX = 15;
-struct FlatBands { int begin[8][16]; };
+struct FlatBands { int begin[8][16]; unsigned rev_mask; };     // rev_mask bit r: stride r (32 workgroups) of every list is walked backwards
 
 struct BlurBatch {
   ImageDesc img[MAX_BATCH];

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   __shared__ unsigned short s_rc[STAGE_TAPS];
   __shared__ unsigned s_wb[STAGE_TAPS];      // weight bits (raw before the division, final after)
   __shared__ int s_flag;
+  __shared__ unsigned s_vg[32];              // scratch of the vertical-run grouping (COMPACT_VRUNS)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *p = reinterpret_cast<const T *>(ptrs.p[blockIdx.x]) + (size_t)tid * EPT;
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(CT) void psf_compact_kernel(PsfPtrs ptrs, int norma
   if (normalize & COMPACT_NO_SEGMENTS) return;  // diagnostics: skip the segmentation
 
   // ---- segmentation (wave 0): dib_compact_dev.h ----
-  segment_taps<false, STAGE_TAPS>(tab, K, normalize, ntaps, (const lds_u16 *)s_rc, (const lds_u32 *)s_wb, lane);
+  segment_taps<false, STAGE_TAPS, false, true>(tab, K, normalize, ntaps, (const lds_u16 *)s_rc, (const lds_u32 *)s_wb, lane, nullptr, (lds_u32 *)s_vg,
+                                               sizeof(T) == 2);
 }
 
 }  // namespace dib
@@ -258,7 +260,8 @@ int dib::compact_launch(const void *const *ptrs, int dtype, int B, int K, int no
     int *t = tables + (size_t)b0 * stride;
     // `normalize` doubles as the flag word: bit 3 (DIB_COMPACT_LARGE_WINDOW) selects the large-window segmentation, anything
     // else that is non-zero means "divide by the sum first"
-    const int flags = ((normalize & ~DIB_COMPACT_LARGE_WINDOW) ? COMPACT_NORMALIZE : 0) | ((normalize & DIB_COMPACT_LARGE_WINDOW) ? COMPACT_LARGE_WINDOW : 0);
+    const int flags = ((normalize & ~(DIB_COMPACT_LARGE_WINDOW | DIB_COMPACT_VRUNS)) ? COMPACT_NORMALIZE : 0) | ((normalize & DIB_COMPACT_LARGE_WINDOW) ? COMPACT_LARGE_WINDOW : 0) |
+                      ((normalize & DIB_COMPACT_VRUNS) ? COMPACT_VRUNS : 0);
     if (dtype == DIB_F16 && K == 128) hipExtLaunchKernelGGL((dib::psf_compact_kernel<__half, 128>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);
     else if (dtype == DIB_F16) hipExtLaunchKernelGGL((dib::psf_compact_kernel<__half, 256>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);
     else if (K == 128) hipExtLaunchKernelGGL((dib::psf_compact_kernel<float, 128>), dim3(n), dim3(dib::CT), 0, s, nullptr, nullptr, lflags, pp, flags, t);

@@ -159,9 +159,11 @@ typedef __attribute__((address_space(3))) lds_vec4 lds_u128;
 // Cuts the row-major tap list into the segments the tiled blur stages in LDS and writes, per tap, its source offset inside
 // that window for both window layouts (ltaps / ltaps_q), the 8 zero words behind them and HDR_NSEGS.  The first STAGE taps are
 // read from LDS (s_rc = row << 8 | col, s_wb = weight bits), later ones from the table's own tap list.
-template <bool WT, int STAGE, bool FIRST = false>   // FIRST: s_first (LDS, 5 words) receives the first entry and the count, as segment_positions leaves them
+// VG (the stand-alone kernel with COMPACT_VRUNS): every closed segment's vertical-run groups go to the table's `vgroups` section
+// (dib_common.h) -- s_vg: 32 words of LDS scratch (per row of the segment: a column bit mask and the index of the row's first tap).
+template <bool WT, int STAGE, bool FIRST = false, bool VG = false>   // FIRST: s_first (LDS, 5 words) receives the first entry and the count, as segment_positions leaves them
 __device__ __forceinline__ void segment_taps(int *tab, int K, int flags, int ntaps, const lds_u16 *s_rc, const lds_u32 *s_wb, int lane,
-                                              lds_int *s_first = nullptr) {
+                                              lds_int *s_first = nullptr, lds_u32 *s_vg = nullptr, bool half_weights = true) {
   const uint2 *taps = reinterpret_cast<const uint2 *>(tab + table_taps_off(K));
   char *segs = reinterpret_cast<char *>(tab + table_segs_off(K));
   unsigned *ltaps = reinterpret_cast<unsigned *>(tab + table_ltaps_off(K));
@@ -178,6 +180,83 @@ __device__ __forceinline__ void segment_taps(int *tab, int K, int flags, int nta
       const int rj = rcj >> 8, cj = rcj & 255;
       st32<WT>(ltaps + j, (unsigned)(((rl - rj) * WIN_PITCH + (cmx - cj)) * 8) | (wj << 16));
       st32<WT>(ltaps_q + j, (unsigned)(((rl - rj) * qpitch + (cmx - cj)) * 8) | (wj << 16));
+    }
+  };
+  // ---- vertical-run groups of a closed segment [s0, s1): rows rf .. rl, columns cmn .. cmx (one wave, all 64 lanes here) ----
+  bool vg_ok = VG && (flags & COMPACT_VRUNS) && !large && half_weights && K == 128;
+  unsigned *vgroups = reinterpret_cast<unsigned *>(tab + table_vgroups_off(K));
+  auto emit_vgroups = [&](int s0, int s1, int rf, int rl, int cmn, int cmx) {
+    if constexpr (VG) {
+      if (!vg_ok) return;
+      if (s1 > STAGE) { vg_ok = false; return; }       // taps beyond the LDS stage: no groups for this table (the blur then refuses FAST16)
+      lds_u32 *s_mask = s_vg;                           // [16] bit c - cmn of word r - rf: the segment has a tap at (r, c)
+      lds_int *s_start = (lds_int *)(s_vg + 16);        // [16] index of the first tap of row r inside the staged list
+      if (lane < 16) { s_mask[lane] = 0u; s_start[lane] = 0x7fffffff; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int b = s0; b < s1; b += 64) {
+        const int j = b + lane;
+        if (j < s1) {
+          const unsigned rc = s_rc[j];
+          __hip_atomic_fetch_or(&s_mask[(rc >> 8) - rf], 1u << ((rc & 255) - cmn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_min(&s_start[(rc >> 8) - rf], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      auto weight_at = [&](int rr, int cc) -> unsigned {       // fp16 weight bits of the segment's tap at (rf + rr, cmn + cc)
+        return s_wb[s_start[rr] + __popc(s_mask[rr] & ((1u << cc) - 1u))] & 0xffffu;
+      };
+      const int nrows = rl - rf + 1;
+      // A run of L taps is cut into L / 4 groups of four and one group of L % 4.  The segment's groups are stored SORTED BY SIZE,
+      // fours first (the tap loop then runs one straight-line body per size: dib_blur.hip), inside a size in the row-major order of
+      // the runs' first taps, a run's fours from its lowest rows up.  Two passes over the taps: count per size, then place.
+      int cnt4 = 0, cnt3 = 0, cnt2 = 0, cnt1 = 0;
+      auto run_of = [&](int j, int &rr, int &cc) -> int {     // length of the run that STARTS at staged tap j (0: j is not a run's first tap)
+        const unsigned rc = s_rc[j];
+        rr = (int)(rc >> 8) - rf; cc = (int)(rc & 255) - cmn;
+        if (rr > 0 && ((s_mask[rr - 1] >> cc) & 1u)) return 0;
+        int L = 1;
+        while (rr + L < nrows && ((s_mask[rr + L] >> cc) & 1u)) ++L;
+        return L;
+      };
+      for (int b = s0; b < s1; b += 64) {
+        const int j = b + lane;
+        int rr = 0, cc = 0;
+        const int L = j < s1 ? run_of(j, rr, cc) : 0;
+        cnt4 += wave_sum_i32(L >> 2);
+        cnt3 += wave_sum_i32((L & 3) == 3); cnt2 += wave_sum_i32((L & 3) == 2); cnt1 += wave_sum_i32((L & 3) == 1);
+      }
+      const int total = cnt4 + cnt3 + cnt2 + cnt1;
+      int base4 = s0, base3 = s0 + cnt4, base2 = base3 + cnt3, base1 = base2 + cnt2;     // next free slot per size
+      // one group of n taps whose highest PSF row is segment row rb, column cc, into slot: its weights (tap j of a group reads window
+      // rows j .. j + 3 from the group's offset: w[0] belongs to the group's HIGHEST PSF row), and its own offset | size into the
+      // PREVIOUS slot's x (the tap loop fetches one group ahead) or, for the segment's first slot, into that slot's own w
+      auto place = [&](int slot, int n, int rb, int cc) {
+        unsigned w[VRUN_MAX] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < VRUN_MAX; ++t)
+          if (t < n) w[t] = weight_at(rb - t, cc);
+        const unsigned own = (unsigned)(((rl - rf - rb) * qpitch + (cmx - cmn - cc)) * 8) | (unsigned)(n - 1) << 16;
+        if (slot > s0) st32<WT>(vgroups + 4 * (size_t)(slot - 1), own);
+        else st32<WT>(vgroups + 4 * (size_t)slot + 3, own);
+        st32<WT>(vgroups + 4 * (size_t)slot + 1, w[0] | w[1] << 16);
+        st32<WT>(vgroups + 4 * (size_t)slot + 2, w[2] | w[3] << 16);
+      };
+      for (int b = s0; b < s1; b += 64) {
+        const int j = b + lane;
+        int rr = 0, cc = 0;
+        const int L = j < s1 ? run_of(j, rr, cc) : 0;
+        const int n4 = L >> 2, rem = L & 3;
+        const int i4 = wave_scan_incl_i32(n4, lane), i3 = wave_scan_incl_i32(rem == 3, lane), i2 = wave_scan_incl_i32(rem == 2, lane),
+                  i1 = wave_scan_incl_i32(rem == 1, lane);
+        for (int g = 0; g < n4; ++g) place(base4 + i4 - n4 + g, 4, rr + 4 * g + 3, cc);
+        if (rem == 3) place(base3 + i3 - 1, 3, rr + L - 1, cc);
+        if (rem == 2) place(base2 + i2 - 1, 2, rr + L - 1, cc);
+        if (rem == 1) place(base1 + i1 - 1, 1, rr + L - 1, cc);
+        base4 += __builtin_amdgcn_readlane(i4, 63); base3 += __builtin_amdgcn_readlane(i3, 63);
+        base2 += __builtin_amdgcn_readlane(i2, 63); base1 += __builtin_amdgcn_readlane(i1, 63);
+      }
+      // behind the last group: the end code (4) in place of a size
+      if (lane == 0) st32<WT>(vgroups + 4 * (size_t)(s0 + total - 1), 4u << 16);
     }
   };
   int nseg = 0, seg_start = 0, seg_r0 = 0, seg_rlast = 0, car_cmin = 1 << 20, car_cmax = -1;
@@ -211,6 +290,7 @@ __device__ __forceinline__ void segment_taps(int *tab, int K, int flags, int nta
         if (FIRST && nseg == 0) { s_first[0] = seg_start; s_first[1] = base + f; s_first[2] = (seg_r0 << 8) | rl; s_first[3] = (cmn << 8) | cmx; }
       }
       emit_ltaps(seg_start, base + f, rl, cmx);
+      emit_vgroups(seg_start, base + f, seg_r0, rl, cmn, cmx);
       ++nseg;
       seg_start = base + f;
       seg_r0 = __builtin_amdgcn_readlane(r, f);
@@ -225,6 +305,7 @@ __device__ __forceinline__ void segment_taps(int *tab, int K, int flags, int nta
       if (FIRST && nseg == 0) { s_first[0] = seg_start; s_first[1] = ntaps; s_first[2] = (seg_r0 << 8) | seg_rlast; s_first[3] = (car_cmin << 8) | car_cmax; }
     }
     emit_ltaps(seg_start, ntaps, seg_rlast, car_cmax);
+    emit_vgroups(seg_start, ntaps, seg_r0, seg_rlast, car_cmin, car_cmax);
     ++nseg;
   } else if (FIRST && lane == 0) {
     s_first[0] = s_first[1] = s_first[2] = s_first[3] = 0;
@@ -232,6 +313,9 @@ __device__ __forceinline__ void segment_taps(int *tab, int K, int flags, int nta
   if (FIRST && lane == 0) s_first[4] = nseg;
   if (lane < 8) { st32<WT>(ltaps + ntaps + lane, 0u); st32<WT>(ltaps_q + ntaps + lane, 0u); }  // the blur's scalar prefetch runs up to two taps past the end
   if (lane == 0) st32<WT>(tab + HDR_NSEGS, (unsigned)nseg);
+  if constexpr (VG) {      // the header's K word again (same lane that wrote it before), now with the groups' validity
+    if (lane == 0) st32<WT>(tab + HDR_K, (unsigned)K | (large ? 1u << 16 : 0u) | ((vg_ok && ntaps > 0) ? HDR_K_VRUNS : 0u));
+  }
 }
 
 // The same cut on the tap POSITIONS alone (one wave; the taps' weights are still being summed and divided by other waves):

@@ -98,6 +98,7 @@ extern "C" int dib_blur_step(const void *const *psf_ptrs, int psf_dtype, int num
     normalize = (normalize ? 1 : 0) | DIB_COMPACT_LARGE_WINDOW;
     acc_mode |= DIB_WINDOW_LARGE;
   }
+  if (acc_mode == DIB_ACC_FAST16) normalize = (normalize ? 1 : 0) | DIB_COMPACT_VRUNS;    // that mode walks the tables' vertical-run groups (always two launches)
   // what an earlier launch on this device left in the status word (a hand-off that timed out, a table of the wrong geometry):
   // reported here, once, without any synchronisation
   if (int rc = consume_device_status("dib_blur_step")) return rc;
@@ -209,6 +210,7 @@ extern "C" int dib_blur_step_ws(const void *const *psf_ptrs, int psf_dtype, int 
     normalize = (normalize ? 1 : 0) | DIB_COMPACT_LARGE_WINDOW;
     acc_mode |= DIB_WINDOW_LARGE;
   }
+  if (acc_mode == DIB_ACC_FAST16) normalize = (normalize ? 1 : 0) | DIB_COMPACT_VRUNS;
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   DIB_HIP_CHECK(hipStreamIsCapturing(s, &cap));

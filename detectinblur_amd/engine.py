@@ -257,6 +257,13 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
     # the update guard of the GPU path (see the loop): only torch's fused SGD takes it; with another optimizer (--foreach_sgd,
     # a caller's own) a non-finite loss still stops the run one step late, that step's update applied
     guard = None
+    if getattr(optimizer, "_dib_found_inf", False):
+        # an earlier epoch left through an exception the caller handled (OOM retry, KeyboardInterrupt) and never reached the
+        # clean-up behind the loop: the attribute is this module's (tagged), and a stale non-zero tensor would make every fused
+        # step from here on a silent no-op
+        if hasattr(optimizer, "found_inf"):
+            del optimizer.found_inf
+        optimizer._dib_found_inf = False
     if isinstance(optimizer, torch.optim.SGD) and all(g.get("fused") for g in optimizer.param_groups) and not hasattr(optimizer, "found_inf"):
         guard = torch.empty(0)
     for images_CPU, targets, blur_dicts in metric_logger.log_every(data_loader, print_freq, header):
@@ -299,6 +306,7 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
             bad = torch.isfinite(losses_reduced.detach()).logical_not().to(torch.float32).reshape(1)
             guard = bad if guard.numel() == 0 else torch.maximum(guard, bad)
             optimizer.found_inf = guard
+            optimizer._dib_found_inf = True
         optimizer.zero_grad()
         losses.backward()
         optimizer.step()
@@ -328,6 +336,7 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch=0, print_freq=2
         _log_step(*deferred)
     if guard is not None and hasattr(optimizer, "found_inf"):
         del optimizer.found_inf
+        optimizer._dib_found_inf = False
     return metric_logger
 
 

@@ -90,7 +90,7 @@ def main(args):
         model = detector(args.resume or args.model_path)
 
     def loader_for(tf):
-        ds, _ = get_coco(args.data_path, "val", tf, synthetic=synthetic)
+        ds, _ = get_coco(args.data_path, "val", tf, synthetic=synthetic, with_masks=getattr(args, "with_masks", False))
         sampler = torch.utils.data.distributed.DistributedSampler(ds) if args.distributed else torch.utils.data.SequentialSampler(ds)
         return torch.utils.data.DataLoader(ds, batch_size=1, sampler=sampler, num_workers=args.workers, collate_fn=utils.collate_fn,
                                            pin_memory=device.type == "cuda", worker_init_fn=_seed_worker, multiprocessing_context=mp_ctx)

@@ -65,7 +65,7 @@ def manual_blur(image_GPU, psf_GPU, add_noise=False, noise_level=0.001, add_bloc
     _check_shapes(image_GPU, K)
     if psf_GPU.dtype != image_GPU.dtype:
         psf_GPU = psf_GPU.to(image_GPU.dtype)   # torch's `roll(image) * psf[r, c]` promotes a 0-dim tensor this way
-    tables = blur_ops.compact_psfs([psf_GPU], normalize=False)
+    tables = blur_ops.compact_psfs([psf_GPU], normalize=False, vruns=acc_mode == _lib.DIB_ACC_FAST16)
     out = blur_ops.sparse_blur([image_GPU], [0], tables, acc_mode)[0]
     out = out.squeeze()
     return _post_ops(out, add_noise, noise_level, add_block, add_jpeg_artifact, jpeg_compressor)
@@ -78,8 +78,12 @@ def blur_image_list(images_GPU, blur_dicts, psfs_GPU, add_noise=False, noise_lev
     PSFs arrive un-normalised and are divided by their sum here (reference :98).  Returns None.
     `tables` (beyond the reference's signature): tap tables of exactly the blurring PSFs, in order, compacted ahead
     of time with blur_ops.compact_psfs_ahead (normalize=True) -- the compaction then overlaps earlier GPU work, and
-    `utils.expand_targets(..., tables=)` can share them.  Without it the PSFs are compacted here, every call, by the one
-    library call that also blurs (`blur_ops.blur_step`: compaction on the library's side stream).
+    `utils.expand_targets(..., tables=)` can share them (what this repo's engine.py does: compaction on a side stream, then
+    `blur_quad_f16_kernel` on the finished tables).  Without it -- the reference's own call, engine.py:101 -- the PSFs are
+    compacted here, every call, by the one library call that also blurs (`blur_ops.blur_step` -> `dib_blur_step`): ONE launch,
+    the grid's first workgroups compact and the blur's workgroups behind them wait inside it (`blur_step_f16_kernel`); a
+    hand-off that ever timed out is reported as a RuntimeWarning and the batch re-issued as two launches (include/dib.h,
+    "Device status").
     `psfs_complete` (beyond the reference's signature as well): the caller states that the PSF tensors are complete when
     this call is made -- e.g. resident PSFs, or the reference's own `torch.HalfTensor(psf).to(device)` (engine.py:84: a
     synchronous copy) -- and not the product of kernels still queued on the current stream; the compaction then need not

@@ -78,6 +78,8 @@ def add_shared_flags(p):
     p.add_argument("--data_path", default=None, help="COCO root (train2017/, val2017/, annotations/)")
     p.add_argument("--synthetic", action="store_true", help="COCO-shaped synthetic data (no dataset on disk needed)")
     p.add_argument("--synthetic_images", default=64, type=int)
+    p.add_argument("--with_masks", action="store_true", help="rasterise the objects' segmentation masks into the targets as the reference's loader does "
+                   "(Faster R-CNN never reads them: off by default, which spares the loader N full-resolution masks per image and the model their resize)")
     p.add_argument("--synthetic_size", default=[800, 1333], nargs=2, type=int)
     p.add_argument("--min_size", default=None, type=int, help="(this repo) FasterRCNN(min_size=), reference default 800 (models/faster_rcnn.py:148)")
     p.add_argument("--max_size", default=None, type=int, help="(this repo) FasterRCNN(max_size=), reference default 1333")
@@ -182,11 +184,11 @@ def main(args):
                   stored_psf_directory=args.stored_psf_directory, dont_center_psf=args.dont_center_psf,
                   high_exposure=args.high_exposure, low_exposure=args.low_exposure, stored_psf_count=args.stored_psf_count)
     dataset, num_classes = get_coco(args.data_path, "train", get_transform(True, blur=args.blur_train, blur_type=blur_type,
-                                                                           blur_ratio=blur_ratio, **common), synthetic=synthetic)
-    dataset_test, _ = get_coco(args.data_path, "val", get_transform(False, blur=False), synthetic=synthetic)
+                                                                           blur_ratio=blur_ratio, **common), synthetic=synthetic, with_masks=args.with_masks)
+    dataset_test, _ = get_coco(args.data_path, "val", get_transform(False, blur=False), synthetic=synthetic, with_masks=args.with_masks)
     eval_blur_type = blur_type if (args.high_exposure and not args.low_exposure) else None        # :164-169
     dataset_test_blur, _ = get_coco(args.data_path, "val", get_transform(False, blur=True, blur_ratio=1, blur_type=eval_blur_type,
-                                                                         **common), synthetic=synthetic)
+                                                                         **common), synthetic=synthetic, with_masks=args.with_masks)
 
     if args.distributed:
         train_sampler = torch.utils.data.distributed.DistributedSampler(dataset)

@@ -83,8 +83,8 @@ def main(args):
                   stored_psf_directory=args.stored_psf_directory, dont_center_psf=args.dont_center_psf,
                   low_exposure=args.low_exposure, high_exposure=args.high_exposure, stored_psf_count=args.stored_psf_count,
                   LEHE_blur_seg=args.LEHE_blur_seg)
-    dataset, _ = get_coco(args.data_path, "train", get_transform(True, **common), synthetic=synthetic)
-    dataset_test, _ = get_coco(args.data_path, "val", get_transform(False, **common), synthetic=synthetic)
+    dataset, _ = get_coco(args.data_path, "train", get_transform(True, **common), synthetic=synthetic, with_masks=False)
+    dataset_test, _ = get_coco(args.data_path, "val", get_transform(False, **common), synthetic=synthetic, with_masks=False)
     if args.distributed:
         train_sampler = torch.utils.data.distributed.DistributedSampler(dataset)
         test_sampler = torch.utils.data.distributed.DistributedSampler(dataset_test, shuffle=False)

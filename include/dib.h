@@ -45,6 +45,13 @@ extern "C" {
 #define DIB_ACC_FP32 1     /* fp32 accumulate, one final rounding (fp16 images only)           */
 #define DIB_ACC_FMA16 2    /* fp16 accumulate with a fused multiply-add: one rounding per tap
                               instead of two; half the arithmetic, not the reference's (fp16 only) */
+#define DIB_ACC_FAST16 3   /* the tolerance mode built for speed: DIB_ACC_FMA16's arithmetic (one fused fp16 multiply-add per
+                              pixel and tap) with the taps of every window REORDERED into vertical runs -- taps of one PSF column
+                              in consecutive rows share their LDS reads -- so the result differs from DIB_ACC_FMA16's in the last
+                              bits (same stated tolerance against the reference: 1e-2 absolute on images in [0, 1]).  fp16 images,
+                              K = 128, standard window (DIB_EINVAL otherwise); a table without the groups (compacted without
+                              DIB_COMPACT_VRUNS, or a PSF of more than 4,096 taps) is blurred in row-major order: DIB_ACC_FMA16's
+                              result */
 /* The LARGE LDS window of the default fp16 tiles (segments of up to 21 PSF rows x 64 columns instead of 13 x 25; 39.9 KB,
  * four workgroups per CU instead of eight): fewer window refills for PSFs that span many columns or rows -- full-exposure
  * trajectories at batch 1, where the grid leaves most workgroup slots empty anyway.  Same results, bit for bit.  A table is
@@ -53,6 +60,9 @@ extern "C" {
  * fp16 images with DIB_ACC_BITEXACT / DIB_ACC_FMA16 only (DIB_EINVAL otherwise). */
 #define DIB_COMPACT_LARGE_WINDOW 8
 #define DIB_WINDOW_LARGE 0x100
+/* or-ed into `normalize` of dib_psf_compact*: also write the table's vertical-run groups, which DIB_ACC_FAST16 reads (fp16 PSFs,
+ * K = 128, standard window; ~1 us more per compaction launch).  Tables without them serve every other mode as before. */
+#define DIB_COMPACT_VRUNS 16
 
 int dib_abi_version(void);
 const char *dib_last_error(void);
@@ -89,6 +99,10 @@ int dib_device_status(int clear);
  * of the default 128-wide tiles (8-byte elements {P[k], P[k+32], P[k+64], P[k+96]}).  With
  * DIB_COMPACT_LARGE_WINDOW the segments are runs of at most 21 rows x 64 columns and ltaps_q holds the
  * large window's offsets; word [5] carries the geometry in bit 16.
+ * | vgroups[K*K] (16-byte records, behind the offsets; with DIB_COMPACT_VRUNS, word [5] bit 17 set when valid): per segment, its
+ * taps regrouped into vertical runs of at most 4 taps of one PSF column in consecutive rows -- record g of a segment whose taps are
+ * [t0, t1) sits at index t0 + g: {LDS offset | taps - 1 << 16 of the NEXT group, w0 | w1 << 16, w2 | w3 << 16, taps - 1 (| own offset
+ * << 2 | groups of the segment << 18 in the segment's first record)}; what the DIB_ACC_FAST16 tap loop walks.
  * ------------------------------------------------------------------------------------- */
 size_t dib_tap_table_bytes(int K); /* bytes of ONE table; K is 128 or 256 */
 /* bytes of the buffer dib_psf_compact fills for B PSFs: B tables, dib_tap_table_bytes(K) apart */

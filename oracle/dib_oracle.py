@@ -320,7 +320,57 @@ def _pad_index(s, n, mode):
     return np.where((s < 0) | (s > n - 1), -1, s)
 
 
-def manual_blur(image, psf_norm, fp32_accumulate=False, fma16=False):
+SEG_ROWS, SEG_COLS = 12, 24      # a tap segment's bounding box: at most 13 PSF rows x 25 columns (include/dib.h, `Tap tables`)
+
+
+def tap_segments(rows, cols, seg_rows=SEG_ROWS, seg_cols=SEG_COLS):
+    """The library's cut of the row-major tap list into the segments its blur stages in LDS (include/dib.h): greedy runs of
+    consecutive taps whose rows span at most seg_rows + 1 and whose columns span at most seg_cols + 1.  Returns [(first, end)].
+    Not the reference's arithmetic -- the reference has no segments -- but what fixes the ORDER in which DIB_ACC_FAST16 adds."""
+    out, start = [], 0
+    n = len(rows)
+    while start < n:
+        r0, cmin, cmax, end = rows[start], cols[start], cols[start], start
+        while end < n:
+            lo, hi = min(cmin, cols[end]), max(cmax, cols[end])
+            if rows[end] - r0 > seg_rows or hi - lo > seg_cols:
+                break
+            cmin, cmax, end = lo, hi, end + 1
+        out.append((start, end))
+        start = end
+    return out
+
+
+def tap_order_vruns(rows, cols):
+    """The order in which DIB_ACC_FAST16 (include/dib.h) accumulates the taps: segment by segment; inside a segment the taps of one
+    PSF column in consecutive rows form a vertical run; a run of L taps is cut, from its lowest row up, into L // 4 groups of four
+    and one group of L % 4; the segment's groups are taken by size -- all fours, then the threes, the twos, the singles -- inside a
+    size in the row-major order of the runs' first taps (a run's fours from its lowest rows up), a group from its lowest row to its
+    highest.  Returns a permutation of range(len(rows))."""
+    order = []
+    for a, b in tap_segments(rows, cols):
+        index = {(int(rows[j]), int(cols[j])): j for j in range(a, b)}
+        by_size = {4: [], 3: [], 2: [], 1: []}
+        for j in range(a, b):
+            r, c = int(rows[j]), int(cols[j])
+            if (r - 1, c) in index:
+                continue
+            run = []
+            while (r, c) in index:
+                run.append(index[(r, c)])
+                r += 1
+            for k in range(0, len(run) - len(run) % 4, 4):
+                by_size[4].append(run[k:k + 4])
+            if len(run) % 4:
+                by_size[len(run) % 4].append(run[len(run) - len(run) % 4:])
+        for n in (4, 3, 2, 1):
+            for g in by_size[n]:
+                order.extend(g)
+    assert sorted(order) == list(range(len(rows)))
+    return order
+
+
+def manual_blur(image, psf_norm, fp32_accumulate=False, fma16=False, tap_order=None):
     """models/blur_functions.py:11-69 (both canvas branches), post-ops excluded.
 
     fp32_accumulate=True restates the library's DIB_ACC_FP32 mode instead of the reference
@@ -329,6 +379,8 @@ def manual_blur(image, psf_norm, fp32_accumulate=False, fma16=False):
     fma16=True restates DIB_ACC_FMA16: acc = fp16(acc + P * w) with ONE rounding per tap (a fused
     multiply-add in fp16).  float64 holds acc + P * w exactly whenever the rounding could go either way
     (22-bit product, 11-bit accumulator), so rounding the float64 sum to fp16 is the fused result.
+    tap_order: a permutation of the row-major tap list, the order to accumulate in (fma16=True with
+    tap_order=tap_order_vruns(rows, cols) restates DIB_ACC_FAST16).
 
     image: C x H x W float16 or float32;  psf_norm: K x K, same dtype, already normalised.
     out[ch,y,x] = sum over taps (r,c), row-major, of  rnd(rnd(P[(y+2pb-r) mod Hp, (x+2pb-c) mod Wp] * w) + acc)
@@ -355,6 +407,8 @@ def manual_blur(image, psf_norm, fp32_accumulate=False, fma16=False):
     rows, cols, wts = taps_of(np.asarray(psf_norm).astype(dt))
     acc = np.zeros((C, H, W), dtype=np.float32 if fp32_accumulate else dt)   # :61
     ys, xs = np.arange(H), np.arange(W)
+    if tap_order is not None:
+        rows, cols, wts = rows[list(tap_order)], cols[list(tap_order)], wts[list(tap_order)]
     for r, c, w in zip(rows, cols, wts):                                  # :66-67
         pr = src_r[(ys + 2 * pb - r) % Hp]
         pc = src_c[(xs + 2 * pb - c) % Wp]

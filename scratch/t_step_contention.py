@@ -9,7 +9,7 @@ with a PSF set that changes every step (a stale table gives other pixels), the B
 every 1,000th step compared bit for bit with compaction + blur as two launches.  Prints per scenario: steps, seconds, the
 device status (0 = no hand-off ever gave up), whether the single launch is still in service, and -- on a -DDIB_STEP_POLLSTATS
 build (scratch/build_variant.sh polls -DDIB_STEP_POLLSTATS; DIB_HIP_LIB=scratch/libdib_hip_polls.so) -- the most polls any
-blur workgroup needed for its first segment / for the counter (the budget is 2^20).
+blur workgroup needed for its first segment / for the counter (waits of more than 32 polls only; the budget is 2^20).
     python scratch/t_step_contention.py [steps per scenario]"""
 import ctypes, os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -10,11 +10,11 @@ from detectinblur_amd import _lib, blur_ops
 
 dev = torch.device("cuda", 0)
 images, dicts, psfs, psfs_host, _ = bench.make_workload(0, dev)
-tables = blur_ops.compact_psfs(psfs, normalize=True)
+tables = blur_ops.compact_psfs(psfs, normalize=True, vruns=True)
 idx = sorted(range(8), key=lambda k: -dicts[k]["psf_taps"])
 native = [torch.rand(3, h, w, generator=torch.Generator().manual_seed(31 + i)).half().to(dev) for i, (h, w) in enumerate(bench.COCO_NATIVE_SIZES)]
 l = _lib.lib(); l.dib_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
-MODE = {"bitexact": _lib.DIB_ACC_BITEXACT, "fma16": _lib.DIB_ACC_FMA16}[os.environ.get("DIB_TL_MODE", "bitexact")]   # DIB_TL_MODE=fma16: the tolerance mode's timeline
+MODE = {"bitexact": _lib.DIB_ACC_BITEXACT, "fma16": _lib.DIB_ACC_FMA16, "fast16": 3}[os.environ.get("DIB_TL_MODE", "bitexact")]   # DIB_TL_MODE=fma16: the tolerance mode's timeline
 
 
 def timeline(name, imgs):

@@ -97,7 +97,7 @@ def test_every_process_gets_a_private_copy_of_the_shipped_miopen_find_db():
     assert not os.path.exists(path)                                   # removed when the process exits
     assert run({"MIOPEN_USER_DB_PATH": "/tmp", "DIB_TEST_PRESET": "1"})[0] == "/tmp"                       # the user's own setting
     # a path exported by THIS module in a parent process (marked by its pid) is not the user's: the child makes its own copy
-    child = run({"MIOPEN_USER_DB_PATH": "/tmp/dib_miopen_db_of_a_parent", "DIB_KERNEL_CHOICES_OWNER": "1", "DIB_TEST_PRESET": "1"})
+    child = run({"MIOPEN_USER_DB_PATH": "/tmp/dib_miopen_db_of_a_parent", "DIB_KERNEL_CHOICES_OWNER": "1:miopen", "DIB_TEST_PRESET": "1"})
     assert "dib_miopen_db_" in child[0] and child[0] != "/tmp/dib_miopen_db_of_a_parent" and child[1] == str(files)
     assert run({"DIB_MIOPEN_DB_INPLACE": "1"})[0] == shipped
     assert run({"DIB_NO_MIOPEN_DB": "1"})[0] == "None"
@@ -130,3 +130,59 @@ def test_every_process_reads_a_private_copy_of_the_shipped_gemm_choices():
     validators = {l.split(",")[1] for l in shipped if l.startswith("Validator,")}
     assert {"PT_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"} <= validators
     assert any("gfx950" in l for l in shipped) and sum(1 for l in shipped if l.startswith("Gemm")) >= 60
+
+
+def test_kernel_choices_marker_names_only_the_variables_this_module_set(tmp_path):
+    import subprocess
+    import sys
+    """ADVICE r5: a user's own MIOPEN_USER_DB_PATH must survive into grandchildren -- the owner marker lists the variable families
+    this module exported, and a child overrides only those."""
+    grandchild = tmp_path / "grandchild.py"
+    grandchild.write_text("import os, sys\nsys.path.insert(0, %r)\nimport detectinblur_amd\ndetectinblur_amd.use_shipped_kernel_choices()\n"
+                          "print(os.environ['MIOPEN_USER_DB_PATH'])\nprint(os.environ['PYTORCH_TUNABLEOP_FILENAME'])\n" % ROOT)
+    child_script = tmp_path / "child.py"
+    child_script.write_text("import os, json, subprocess, sys\nsys.path.insert(0, %r)\nimport detectinblur_amd\ndetectinblur_amd.use_shipped_kernel_choices()\n"
+                            "own = os.environ['DIB_KERNEL_CHOICES_OWNER']\n"
+                            "g = subprocess.run([sys.executable, %r], capture_output=True, text=True)\n"
+                            "print(json.dumps([own, os.environ['MIOPEN_USER_DB_PATH'], os.environ.get('PYTORCH_TUNABLEOP_FILENAME'), g.stdout.split()]))\n"
+                            % (ROOT, str(grandchild)))
+    mine = str(tmp_path / "my_miopen_db")
+    os.makedirs(mine)
+    env = {k: v for k, v in os.environ.items() if k not in ("DIB_KERNEL_CHOICES_OWNER", "MIOPEN_USER_DB_PATH") and not k.startswith("PYTORCH_TUNABLEOP")}
+    env["MIOPEN_USER_DB_PATH"] = mine
+    import json
+    p = subprocess.run([sys.executable, str(child_script)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    own, parent_db, parent_csv, child = json.loads(p.stdout.strip().splitlines()[-1])
+    assert own.split(":")[1] == "tunableop"                     # the find-db variable was the user's: not claimed
+    assert parent_db == mine and child[0] == mine               # ... and it reaches the grandchild untouched
+    assert child[1] != parent_csv and "dib_tunableop_" in child[1]    # the TunableOp copy WAS this module's: the child made its own
+
+
+def test_kernel_choices_fill_tool_plumbing(tmp_path):
+    import sys
+    """`python -m detectinblur_amd.kernel_choices --fill`: a fresh child per shape set whose MIOpen user db and TunableOp file live
+    in the output directory, seeded from the package, installed on request.  The worker is a stub here (no GPU)."""
+    from detectinblur_amd import kernel_choices as kc
+    pkg = tmp_path / "pkg"
+    (pkg / "miopen_db").mkdir(parents=True)
+    (pkg / "tunableop").mkdir()
+    (pkg / "miopen_db" / "old.ufdb.txt").write_text("old\n")
+    (pkg / "tunableop" / "tunableop_results.csv").write_text("Validator,PT_VERSION,x\n")
+    stub = tmp_path / "stub.py"
+    stub.write_text("import os, sys\n"
+                    "assert os.environ['DIB_NO_MIOPEN_DB'] == '1' and os.environ['PYTORCH_TUNABLEOP_TUNING'] == '1' and 'DIB_KERNEL_CHOICES_OWNER' not in os.environ\n"
+                    "d = os.environ['MIOPEN_USER_DB_PATH']\n"
+                    "open(os.path.join(d, 'new.ufdb.txt'), 'a').write(sys.argv[1] + os.environ.get('MIOPEN_FIND_ENFORCE', '-') + '\\n')\n"
+                    "f = os.environ['PYTORCH_TUNABLEOP_FILENAME'].replace('.csv', '0.csv')\n"
+                    "assert open(f).read().startswith('Validator')\n"
+                    "open(f, 'a').write('GemmTunableOp,%s\\n' % sys.argv[1])\n")
+    res = kc.fill(["bench", "coco-eval"], str(tmp_path / "out"), tune=True, install=True, package_dir=str(pkg),
+                  worker_argv=lambda name, tune: [sys.executable, str(stub), name])
+    assert res["returncodes"] == {"bench": 0, "coco-eval": 0}
+    assert res["miopen"] == ["new.ufdb.txt", "old.ufdb.txt"] and res["installed_into"] == str(pkg)
+    assert (pkg / "miopen_db" / "new.ufdb.txt").read_text() == "bench3\ncoco-eval3\n"
+    assert (pkg / "tunableop" / "tunableop_results.csv").read_text() == "Validator,PT_VERSION,x\nGemmTunableOp,bench\nGemmTunableOp,coco-eval\n"
+    assert kc.foreign_hint({"miopen_foreign_files": ["x.ufdb.txt"]}).endswith(kc.FILL_COMMAND)
+    assert kc.foreign_hint({"miopen_foreign_files": [], "tunableop_validators_match": True}) is None
+    assert set(kc.SHAPE_SETS) == {"bench", "coco-train", "coco-eval"}

@@ -229,6 +229,17 @@ def test_non_finite_loss_leaves_the_reference_s_weights_gpu(pins, arrays):
     model, opt, text, code = _run_nonfinite(torch.device("cuda"), lambda m: utils.make_sgd(m.parameters(), lr=0.04, momentum=0.9, weight_decay=1e-4))
     assert all(g.get("fused") for g in opt.param_groups)
     _check_nonfinite(model, opt, text, code, pins, arrays, 1e-5, pins["train"]["nonfinite"]["steps"] + 1)
+    # The loop left through SystemExit with its update guard still attached to the optimizer (a caller may catch that and go on:
+    # ADVICE r5).  The next epoch on the same optimizer must not keep the stale, non-zero guard -- every fused step would be a
+    # silent no-op -- so the attribute is tagged as the loop's own and dropped at entry.
+    from detectinblur_amd import engine
+    assert getattr(opt, "_dib_found_inf", False) and hasattr(opt, "found_inf")
+    before = [p.detach().clone() for g in opt.param_groups for p in g["params"]]
+    with contextlib.redirect_stdout(io.StringIO()):
+        engine.train_one_epoch(model, opt, PI.train_batches(False), torch.device("cuda"), epoch=1, print_freq=2, writer=PI.RecordingWriter(),
+                               distributed_mode=True, early_stop=None)
+    assert not hasattr(opt, "found_inf") and not opt._dib_found_inf
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, [p for g in opt.param_groups for p in g["params"]]))
 
 
 # ---- A17: evaluate (reference engine.py:220-416) -----------------------------------------------------------------------------

@@ -35,7 +35,7 @@ def test_shipped_choices_belong_to_the_running_miopen_and_pytorch():
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("REPORT ")][-1][7:])
     assert r["installed"] and r["miopen_user_db"]
     # MIOpen wrote under the shipped files' names: they belong to this build.  A foreign name here means the shipped data is dead
-    # weight on this stack: regenerate it (scratch/fill_miopen_db.sh, scratch/tune_miopen_train.sh).
+    # weight on this stack: regenerate it (`python -m detectinblur_amd.kernel_choices --fill --shapes all --install`; the report says so itself).
     assert r["miopen_foreign_files"] == [], r
     assert r["tunableop_validators_match"] is True, r
     assert r["tunableop_entries_loaded"] >= r["tunableop_shipped_entries"] >= 60, r
