@@ -173,7 +173,7 @@ _raw_stream = None
 
 def stream_of(tensor):
     """hipStream_t (as an int) of torch's current stream on the tensor's device.  torch's raw accessor is ~30x cheaper than building
-    a torch.cuda.Stream object (8 us of host time per call: measured, scratch/t_detect_cost.py), which is most of a small launch."""
+    a torch.cuda.Stream object (8 us of host time per call: measured in round 4), which is most of a small launch."""
     global _raw_stream
     import torch
     if _raw_stream is None:

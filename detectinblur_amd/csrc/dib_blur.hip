@@ -568,18 +568,15 @@ static_assert(QGeom<true>::PITCH == 768 && QGeom<true>::ROWS % NW == 0 && QGeom<
 #define DIBQ_FMADDH_Y(W) DIBQ_FMA(40, 0, W) DIBQ_FMA(42, 2, W) DIBQ_FMA(44, 4, W) DIBQ_FMA(46, 6, W)
 #define DIBQ_LOAD(PAIR) "s_load_dwordx2 " PAIR ", %10, %8\n\ts_add_u32 %8, %8, 8\n\t"
 #define DIBQ_NEXT(LABEL) "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 " LABEL "\n\t"
-// NOVM: no vmcnt wait in front of the first LDS read -- the pipelined kernel (blur_fast16_pipe_kernel) enters with the NEXT window's
-// loads in flight on purpose (their values are used behind the loop, so hipcc keeps their registers out of the clobber list)
-template <bool FUSED, bool HALF, bool L = false, bool NOVM = false>
+template <bool FUSED, bool HALF, bool L = false>
 __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
   unsigned a[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
-#define DIB_RQ_ASM(RD, ARITH_X, ARITH_Y) DIB_RQ_ASM2(RD, ARITH_X, ARITH_Y, "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
-#define DIB_RQ_ASM2(RD, ARITH_X, ARITH_Y, WAIT0) \
+#define DIB_RQ_ASM(RD, ARITH_X, ARITH_Y) \
   asm volatile( \
-      DIBQ_LOAD("s[36:37]") DIBQ_LOAD("s[38:39]") WAIT0 RD(32, "s36") \
+      DIBQ_LOAD("s[36:37]") DIBQ_LOAD("s[38:39]") "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" RD(32, "s36") \
       "Ldibq_loop%=:\n\t" \
       "s_waitcnt lgkmcnt(0)\n\t" DIBQ_LOAD("s[40:41]") RD(40, "s37") ARITH_X("s36") DIBQ_NEXT("Ldibq_done%=") \
       "s_waitcnt lgkmcnt(0)\n\t" RD(32, "s38") ARITH_Y("s37") DIBQ_NEXT("Ldibq_done%=") \
@@ -594,9 +591,7 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
       : "s"(ltaps), "v"(lane_addr) \
       : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", \
         "s36", "s37", "s38", "s39", "s40", "s41", "scc", "memory")
-  if constexpr (NOVM && FUSED && !L && HALF) { DIB_RQ_ASM2(DIBQ_READH, DIBQ_FMADDH_X, DIBQ_FMADDH_Y, "s_waitcnt lgkmcnt(0)\n\t"); }
-  else if constexpr (NOVM && FUSED && !L) { DIB_RQ_ASM2(DIBQ_READ, DIBQ_FMADD_X, DIBQ_FMADD_Y, "s_waitcnt lgkmcnt(0)\n\t"); }
-  else if constexpr (L && FUSED && HALF) { DIB_RQ_ASM(DIBQ_READH_L, DIBQ_FMADDH_X, DIBQ_FMADDH_Y); }
+  if constexpr (L && FUSED && HALF) { DIB_RQ_ASM(DIBQ_READH_L, DIBQ_FMADDH_X, DIBQ_FMADDH_Y); }
   else if constexpr (L && FUSED) { DIB_RQ_ASM(DIBQ_READ_L, DIBQ_FMADD_X, DIBQ_FMADD_Y); }
   else if constexpr (L && HALF) { DIB_RQ_ASM(DIBQ_READH_L, DIBQ_MADDH_X, DIBQ_MADDH_Y); }
   else if constexpr (L) { DIB_RQ_ASM(DIBQ_READ_L, DIBQ_MADD_X, DIBQ_MADD_Y); }
@@ -605,7 +600,6 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
   else if constexpr (HALF) { DIB_RQ_ASM(DIBQ_READH, DIBQ_MADDH_X, DIBQ_MADDH_Y); }
   else { DIB_RQ_ASM(DIBQ_READ, DIBQ_MADD_X, DIBQ_MADD_Y); }
 #undef DIB_RQ_ASM
-#undef DIB_RQ_ASM2
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
 }
@@ -726,19 +720,18 @@ __device__ __forceinline__ void tap_loop_quad_fp32(float (&acc)[16], unsigned lo
   "s_cmp_eq_u32 s46, 2\n\ts_cbranch_scc1 Lvr_c3" P "%=\n\t"                                                 \
   "s_cmp_eq_u32 s46, 1\n\ts_cbranch_scc1 Lvr_c2" P "%=\n\t"                                                 \
   "s_branch Lvr_c1" P "%=\n\t"
-template <bool HALF, bool NOVM = false>
+template <bool HALF>
 __device__ __forceinline__ void tap_loop_quad_vrun(h2 (&acc)[8], unsigned long long vgroups, int g0, unsigned lane_addr) {
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(g0 * 16);
   unsigned a[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(unsigned, acc[i]);
-#define DIB_VR_ASM(RD, TAP) DIB_VR_ASM2(RD, TAP, "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
-#define DIB_VR_ASM2(RD, TAP, WAIT0) \
+#define DIB_VR_ASM(RD, TAP) \
   asm volatile( \
       /* the segment's first record: its own offset and size sit in w; its rows are requested for the largest size (rows past a \
          smaller group's are read and not used: the window's own rows, or zeros past the workgroup's LDS) */ \
       "s_load_dwordx4 s[36:39], %9, %8\n\ts_add_u32 %8, %8, 16\n\t" \
-      WAIT0 \
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
       "s_bfe_u32 s46, s39, 0x30010\n\t" \
       VR_READS4(RD, 32, "s39") \
       "s_branch Lvr_dx%=\n\t" \
@@ -751,12 +744,9 @@ __device__ __forceinline__ void tap_loop_quad_vrun(h2 (&acc)[8], unsigned long l
       : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", \
         "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s46", \
         "scc", "memory")
-  if constexpr (NOVM && HALF) { DIB_VR_ASM2(VR_RDH, VR_TAPH, "s_waitcnt lgkmcnt(0)\n\t"); }
-  else if constexpr (NOVM) { DIB_VR_ASM2(VR_RD, VR_TAP, "s_waitcnt lgkmcnt(0)\n\t"); }
-  else if constexpr (HALF) { DIB_VR_ASM(VR_RDH, VR_TAPH); }
+  if constexpr (HALF) { DIB_VR_ASM(VR_RDH, VR_TAPH); }
   else { DIB_VR_ASM(VR_RD, VR_TAP); }
 #undef DIB_VR_ASM
-#undef DIB_VR_ASM2
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = __builtin_bit_cast(h2, a[i]);
 }
@@ -844,9 +834,6 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   if (!L && !STEP && wave == 0 && fresh_lane() == 0)
     *(__attribute__((address_space(3))) unsigned long long *)(size_t)(lds0 + QGeom<false>::BYTES + 32) = __builtin_amdgcn_s_memrealtime();
 #endif
-#ifdef DIB_FILL_PRIO
-  __builtin_amdgcn_s_setprio(DIB_FILL_PRIO);      // experiment (docs/experiments.md): prologue + window fill ahead of the older waves' tap loops
-#endif
   for (int sg = 0; sg < (STEP ? (nsegs & 0xffffff) : nsegs); ++sg) {
     if (sg > 0) seg = segs[sg];
     const Window w = window_of(seg);
@@ -900,11 +887,7 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
         if (part * GP + g >= GQ) continue;
         const int so = __builtin_amdgcn_readfirstlane(soff[part * GP + g]);
 #pragma unroll
-#ifdef DIB_EXP_NOFILL      /* experiment: what the launch costs without its window loads (garbage pixels) */
-        for (int k = 0; k < NK; ++k) v[g][k] = (short)(so + k);
-#else
         for (int k = 0; k < NK; ++k) v[g][k] = __builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);
-#endif
       }
 #ifdef DIB_TIMELINE
       if (!L && !STEP && sg == 0 && part == 0 && wave == 0 && fresh_lane() == 0)
@@ -968,18 +951,11 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       *(__attribute__((address_space(3))) unsigned long long *)(size_t)(lds0 + QGeom<false>::BYTES + 16) = __builtin_amdgcn_s_memrealtime();
 #endif
     if constexpr (STEP) { if (sg == 0 && (nsegs >> 30)) wait_tables(); }
-#ifdef DIB_FILL_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     const int tl = fresh_lane();
     const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
     if constexpr (ACC == DIB_ACC_FP32) {
       if (W - x0f() <= 64) tap_loop_quad_fp32<true, L>(acc32, ltaps, w.t0, w.n, lane_addr);
       else tap_loop_quad_fp32<false, L>(acc32, ltaps, w.t0, w.n, lane_addr);
-#ifdef DIB_EXP_NOTAPS      /* experiment: the launch without its tap loops (fill + store only) */
-    } else if constexpr (ACC == DIB_ACC_FAST16 || ACC == DIB_ACC_FMA16) {
-      acc[0] = __builtin_bit_cast(h2, *(__attribute__((address_space(3))) unsigned *)(size_t)lane_addr);
-#endif
     } else if constexpr (ACC == DIB_ACC_FAST16) {
       // the segment's vertical-run groups: records from index t0 on (dib_common.h: vgroups)
       const unsigned long long va = (unsigned long long)(tab + table_vgroups_off(K));
@@ -1031,10 +1007,6 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       }
     }
   } else {
-#ifdef DIB_EXP_NOSTORE     /* experiment: the launch without its stores (one lane keeps the accumulators alive) */
-    if (acc[0].x == (_Float16)12345.f && acc[7].y == (_Float16)-777.f) *(volatile int *)d.out = 1;
-    return;
-#endif
     // STEP: the plane offset ch * H * W * 2 is formed again here (from an opaque copy of ch) instead of staying alive from the
     // input descriptor's across the segment loop: two scalar registers the step kernel does not have (it spilled them).
     int chs = ch;
@@ -1093,12 +1065,7 @@ constexpr int TL_WORD = QLDS_BYTES / 4;
 // proportion (8 waves per SIMD: ~10 cycles per instruction and wave, times 3.2 rounds of workgroups).
 // FLAT (ragged batches, dib_common.h: FlatBands): a 1-D grid of exactly the working workgroups; the image comes from one more
 // scalar load (the XCD list's 16 entry offsets) in front of the descriptor's.
-// TPW (tiles per workgroup; > 1 on the 2-D grid of DIB_ACC_FAST16 only): a workgroup computes TPW consecutive tiles of its band one
-// after the other.  That mode is bound by what a workgroup's LIFE costs -- eight slots per CU, a slot's phases (dispatch gap,
-// prologue, window fill, taps, store) one after the other: the launch time is their SUM (scratch ablations: skeleton 10.9 + loads
-// 9.4 + taps 10.8 + stores 4.0 us against 31.5 us measured) -- and the second tile pays neither the ~0.9 us between a workgroup's
-// end and the next one's start on its slot nor the descriptor's scalar round trip.
-template <int ACC, int KC, bool FLAT = false, int TPW = 1>
+template <int ACC, int KC, bool FLAT = false>
 __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, FlatBands fb) {
   constexpr int K = KC;
   extern __shared__ unsigned nlds[];
@@ -1143,19 +1110,6 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
                "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab));
   const int per_ch = d.tiles_x * d.tiles_y;
   int local;
-  if constexpr (TPW > 1) {
-    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-#pragma unroll 1
-    for (int k = 0; k < TPW; ++k) {
-      if (!band_entry(d.C * per_ch, blockIdx.x & 7, entry * TPW + k, local)) break;
-      const int ch = magic_div(local, d.inv_per_ch);
-      local -= ch * per_ch;
-      const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-      if (k > 0) __syncthreads();          // every wave is done with the previous tile's window
-      blur_quad_tile_f16<ACC>(d, d.tab, K, ch, tx, ty, lds_addr(nlds), wv);
-    }
-    return;
-  }
   if (!band_entry(d.C * per_ch, blockIdx.x & 7, entry, local)) return;
   const int ch = magic_div(local, d.inv_per_ch);
   local -= ch * per_ch;
@@ -1176,223 +1130,6 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
     }
   }
 #endif
-}
-
-// =============================================================================================
-// DIB_ACC_FAST16, PIPELINED: persistent workgroups, two LDS windows, the next window's loads in flight under this window's taps.
-// With half the arithmetic per tap the default kernel is no longer bound by the vector ALU but by what a workgroup's LIFE costs:
-// eight slots per CU, and in every slot dispatch gap -> prologue -> window loads -> taps -> store strictly one after the other --
-// the launch time is the SUM of those phases (measured by leaving them out one at a time: skeleton 10.9 + loads 9.4 + taps 10.8 +
-// stores 4.0 us against 31.5 us; docs/experiments.md).  Here a workgroup stays (four per CU: 2 x 19.7 KB of LDS, 128 registers per
-// lane) and walks its share of its XCD's tile list; per window (a tile's segment):
-//     request the NEXT window's 44 values per lane (they stay in registers across the tap loop)
-//     tap loop on THIS window's LDS buffer; after a tile's last segment: store
-//     the next window's values -> the OTHER LDS buffer; one barrier
-// so a wave waits for memory only where its own arithmetic was shorter than the round trip.  Round 2 built this shape for the
-// bit-exact arithmetic and lost (the vector ALU was the wall and the look-ahead cost occupancy); with the fused arithmetic the
-// wall is latency.  Same windows, same loops, same order of additions as blur_quad_f16_kernel<DIB_ACC_FAST16>: bit-identical.
-// Grid: 8 x min(128, longest list) workgroups; workgroup b walks entries (b >> 3), + stride, ... of list b & 7 (FlatBands).
-// =============================================================================================
-struct PipeTile {       // what stays of a tile while its windows pass
-  const void *in; void *out; const int *tab;
-  int H, W, ch, x0, y0, nsegs, use_vruns, empty;     // empty: a PSF without taps (one window, no tap loop: the tile becomes zeros)
-};
-struct PipeSeg { int t0, n, rf, rl, cmin, cmax; };
-constexpr int PIPE_LDS_BYTES = 2 * QLDS_BYTES;
-
-__global__ __launch_bounds__(256, 4) void blur_fast16_pipe_kernel(BlurBatch batch, FlatBands fb) {
-#pragma clang fp contract(off)
-  constexpr int K = 128, GQ = QGeom<false>::GQ, pb = K / 2 - 1, pa = K / 2;
-  extern __shared__ unsigned nlds[];
-  const unsigned lds0 = lds_addr(nlds);
-  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  typedef int i16v __attribute__((ext_vector_type(16)));
-  const i16v bb = *reinterpret_cast<const i16v *>(fb.begin[blockIdx.x & 7]);
-  const int len = bb[15], stride = (int)(gridDim.x >> 3);
-  typedef unsigned lds_u2v __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) lds_u2v lds_u2;
-
-  // ---- the windows of this workgroup, in order: (entry, segment) ----
-  auto tile_of = [&](int entry, PipeTile &t) {
-    int start = bb[0], img_i = 0;
-#pragma unroll
-    for (int k = 1; k < FLAT_MAX; ++k) {
-      const bool ge = entry >= bb[k];
-      img_i += ge ? 1 : 0;
-      start = ge ? bb[k] : start;
-    }
-    const ImageDesc d = batch.img[img_i];
-    const int per_ch = d.tiles_x * d.tiles_y;
-    int local;
-    band_entry(d.C * per_ch, blockIdx.x & 7, entry - start, local);      // inside the band by construction of the list
-    const int ch = magic_div(local, d.inv_per_ch);
-    local -= ch * per_ch;
-    const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-    t.in = d.in; t.out = d.out; t.tab = d.tab; t.H = d.H; t.W = d.W; t.ch = ch; t.x0 = tx * QTILE_W; t.y0 = ty * TH;
-    const int hk = d.tab[HDR_K], ns = d.tab[HDR_NSEGS];
-    t.empty = ns == 0;
-    t.nsegs = ns == 0 ? 1 : ns;
-    t.use_vruns = (hk >> 17) & 1;
-  };
-  auto seg_of = [&](const PipeTile &t, int sg, PipeSeg &o) {
-    uint4 q = reinterpret_cast<const uint4 *>(t.tab + table_segs_off(K))[sg];
-    if (t.empty) q = make_uint4(0u, 0u, (63u << 8) | 63u, (63u << 8) | 63u);
-    o.t0 = (int)q.x; o.n = (int)(q.y - q.x); o.rf = (int)(q.z >> 8); o.rl = (int)(q.z & 255); o.cmin = (int)(q.w >> 8); o.cmax = (int)(q.w & 255);
-  };
-  // ---- fill, part 1: this wave's 11 rows x 4 values of window (t, s), requested (blur_quad_tile_f16's fill, PAD_REFLECT / PAD_ZERO) ----
-  auto issue = [&](const PipeTile &t, const PipeSeg &sgm, unsigned (&v)[GQ][4], unsigned &zmask) {
-    const int H = t.H, W = t.W, w2 = W * 2, mode = pad_mode_for(K, H, W), qb = wave * GQ;
-    const __amdgpu_buffer_rsrc_t in_rsrc = plane_rsrc(t.in, t.ch, H, W);
-    unsigned coff[4];
-    int soff[GQ];
-    zmask = 0;
-    const int c_first = t.x0 + pb - sgm.cmax, r_first = t.y0 + pb - sgm.rl;
-    const bool zero_mode = mode == PAD_ZERO;
-    if (!zero_mode && c_first >= 0 && c_first + 63 + 96 <= W - 1) {
-      const unsigned c0 = 2u * (unsigned)(c_first + lane);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) coff[k] = c0 + 64u * k;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        bool z;
-        coff[k] = 2u * (unsigned)map_coord_sel(c_first + lane + 32 * k, W, pa, pb, mode, z);
-        zmask |= z ? 1u << k : 0u;
-      }
-    }
-    if (!zero_mode && r_first >= 0 && r_first + LROWS - 1 <= H - 1) {
-      const int s0 = (r_first + qb) * w2;
-#pragma unroll
-      for (int g = 0; g < GQ; ++g) soff[g] = s0 + g * w2;
-    } else {
-      const int nrows = TH + (sgm.rl - sgm.rf);
-#pragma unroll
-      for (int g = 0; g < GQ; ++g) {
-        bool zr;
-        const int sr = map_coord_sel(r_first + min(qb + g, nrows - 1), H, pa, pb, mode, zr);
-        zmask |= zr ? 1u << (8 + g) : 0u;
-        soff[g] = sr * w2;
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < GQ; ++g) {
-      const int so = __builtin_amdgcn_readfirstlane(soff[g]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[g][k] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(in_rsrc, coff[k], so, 0);   // (the load zero-extends)
-    }
-  };
-  // ---- fill, part 2: the values -> this wave's rows of the LDS window at `base` ----
-  auto write = [&](unsigned base, unsigned (&v)[GQ][4], unsigned zmask) {
-    // The values were requested a tap loop ago and must stay 44 separate registers in flight until here: without this fence hipcc
-    // hoists the packing below to right behind the loads and waits for every one of them there -- in front of the tap loop they
-    // were meant to hide behind.
-#pragma unroll
-    for (int g = 0; g < GQ; ++g) asm volatile("" : "+v"(v[g][0]), "+v"(v[g][1]), "+v"(v[g][2]), "+v"(v[g][3]));
-    const bool masked = __builtin_amdgcn_ballot_w64(zmask != 0) != 0;
-    const unsigned wp = base + (unsigned)((wave * GQ) * QPITCH + lane * 8);
-    if (lane < QUAD_PITCH) {
-#pragma unroll
-      for (int g = 0; g < GQ; ++g) {
-        lds_u2v e;
-        if (!masked) {
-          e.x = v[g][0] | (v[g][1] << 16);
-          e.y = v[g][2] | (v[g][3] << 16);
-        } else {
-          unsigned u[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) u[k] = (((zmask >> k) & 1u) || ((zmask >> (8 + g)) & 1u)) ? 0u : v[g][k];
-          e.x = u[0] | (u[1] << 16);
-          e.y = u[2] | (u[3] << 16);
-        }
-        *(lds_u2 *)(size_t)(wp + (unsigned)(g * QPITCH)) = e;
-      }
-    }
-  };
-  // ---- store of a finished tile (blur_quad_tile_f16's store phase) ----
-  auto store = [&](const PipeTile &t, const h2 (&acc)[8]) {
-    const int H = t.H, W = t.W, w2 = W * 2, x0 = t.x0, y0 = t.y0;
-    const int yl = y0 + wave * 8 + (lane >> 5) * 4, xl = x0 + (lane & 31);
-    const unsigned base = (unsigned)(yl * w2 + xl * 2), oob = 0x7ffffff0u;
-    if (x0 + QTILE_W <= W && y0 + TH <= H) {
-      typedef int i4v __attribute__((ext_vector_type(4)));
-      const unsigned long long pa2 = (unsigned long long)t.out + (unsigned long long)t.ch * H * W * 2ull;
-      const i4v rs = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa2), __builtin_amdgcn_readfirstlane((int)(unsigned)(pa2 >> 32)) & 0xffff,
-                      H * W * 2, 0x00020000};
-      int so = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        asm volatile("buffer_store_short %0, %2, %3, %4 offen\n\t"
-                     "buffer_store_short_d16_hi %0, %2, %3, %4 offen offset:64\n\t"
-                     "buffer_store_short %1, %2, %3, %4 offen offset:128\n\t"
-                     "buffer_store_short_d16_hi %1, %2, %3, %4 offen offset:192"
-                     :: "v"(acc[2 * i]), "v"(acc[2 * i + 1]), "v"(base), "s"(rs), "s"(so) : "memory");
-        so += w2;
-      }
-      return;
-    }
-    const __amdgpu_buffer_rsrc_t out_rsrc = plane_rsrc(t.out, t.ch, H, W);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool row_ok = yl + i < H;
-      const unsigned a0 = __builtin_bit_cast(unsigned, acc[2 * i]), a1 = __builtin_bit_cast(unsigned, acc[2 * i + 1]);
-      const unsigned ro = base + (unsigned)(i * w2);
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a0 & 0xffffu), out_rsrc, row_ok && xl < W ? ro : oob, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a0 >> 16), out_rsrc, row_ok && xl + 32 < W ? ro + 64u : oob, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a1 & 0xffffu), out_rsrc, row_ok && xl + 64 < W ? ro + 128u : oob, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b16((short)(a1 >> 16), out_rsrc, row_ok && xl + 96 < W ? ro + 192u : oob, 0, 0);
-    }
-  };
-
-  int e = (int)(blockIdx.x >> 3);
-  if (e >= len) return;
-  PipeTile tc, tn;          // the tile of the window being multiplied / of the window being fetched
-  PipeSeg sc, sn;
-  int sgn = 0;              // segment index of the window being fetched
-  unsigned v[GQ][4];
-  unsigned zmask;
-  h2 acc[8];
-  // window 0 -> buffer 0
-  tile_of(e, tn);
-  seg_of(tn, 0, sn);
-  issue(tn, sn, v, zmask);
-  write(lds0, v, zmask);
-  __syncthreads();
-  unsigned buf = 0;
-  bool more = true;
-  while (more) {
-    tc = tn; sc = sn;
-    const int sgc = sgn;
-    // the next window: this tile's next segment, or the first segment of the next entry
-    if (sgn + 1 < tn.nsegs) { ++sgn; seg_of(tn, sgn, sn); }
-    else { e += stride; more = e < len; if (more) { tile_of(e, tn); sgn = 0; seg_of(tn, 0, sn); } }
-    if (more) issue(tn, sn, v, zmask);
-    if (sgc == 0) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = h2{0, 0};
-    }
-    const unsigned base = lds0 + buf * (unsigned)QLDS_BYTES;
-    const unsigned lane_addr = base + (unsigned)((wave * 8 + (lane >> 5) * 4) * QPITCH + (lane & 31) * 8);
-    const bool half = tc.W - tc.x0 <= 64;
-    if (tc.empty) {
-    } else if (tc.use_vruns) {
-      const unsigned long long va = (unsigned long long)(tc.tab + table_vgroups_off(K));
-      const unsigned long long vg = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(va >> 32)) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)va);
-      if (half) tap_loop_quad_vrun<true, true>(acc, vg, sc.t0, lane_addr);
-      else tap_loop_quad_vrun<false, true>(acc, vg, sc.t0, lane_addr);
-    } else {
-      const unsigned long long la = (unsigned long long)(tc.tab + table_ltaps_q_off(K));
-      const unsigned long long lt = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(la >> 32)) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)la);
-      if (half) tap_loop_quad<true, true, false, true>(acc, lt, sc.t0, sc.n, lane_addr);
-      else tap_loop_quad<true, false, false, true>(acc, lt, sc.t0, sc.n, lane_addr);
-    }
-    if (sgc + 1 == tc.nsegs) store(tc, acc);
-    if (more) write(lds0 + (buf ^ 1u) * (unsigned)QLDS_BYTES, v, zmask);
-    __syncthreads();          // the next window is complete; everybody is done with this one
-    buf ^= 1u;
-  }
 }
 
 // =============================================================================================
@@ -1785,14 +1522,6 @@ extern "C" void dib_debug_set_flat_grid(int on) { g_flat_grid = on ? 1 : 0; }
 // ... and on it, every other stride of 32 workgroups of an XCD's list walked backwards (default; 0 in A/B runs)
 static int g_flat_snake = !(getenv("DIB_FLAT_SNAKE") && getenv("DIB_FLAT_SNAKE")[0] == '0');
 extern "C" void dib_debug_set_flat_snake(int on) { g_flat_snake = on ? 1 : 0; }
-// DIB_ACC_FAST16 on the 2-D grid: tiles a workgroup computes one after the other (1 .. 4; DIB_FAST16_TPW)
-static int tpw_from_env() { const char *e = getenv("DIB_FAST16_TPW"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 4 ? v : 1; }
-static int g_fast16_tpw = tpw_from_env();
-extern "C" void dib_debug_set_fast16_tpw(int n) { g_fast16_tpw = n >= 1 && n <= 4 ? n : 1; }
-// DIB_ACC_FAST16 through the pipelined kernel (persistent workgroups, two LDS windows); slots: workgroups per XCD
-static int g_fast16_pipe = getenv("DIB_FAST16_PIPE") ? atoi(getenv("DIB_FAST16_PIPE")) : 0;
-static int g_fast16_pipe_slots = getenv("DIB_FAST16_PIPE_SLOTS") ? atoi(getenv("DIB_FAST16_PIPE_SLOTS")) : 128;
-extern "C" void dib_debug_set_fast16_pipe(int on, int slots) { g_fast16_pipe = on ? 1 : 0; if (slots > 0) g_fast16_pipe_slots = slots; }
 static int g_flat_mask = -1;      // experiments: an explicit stride mask
 extern "C" void dib_debug_set_flat_mask(int mask) { g_flat_mask = mask; }
 
@@ -1836,10 +1565,6 @@ int prepare_device() {
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 128, true>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, true>), QLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in(blur_fast16_pipe_kernel, PIPE_LDS_BYTES));
-    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 2>), QLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 3>), QLDS_BYTES + TL_EXTRA));
-    DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 4>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_BITEXACT, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_kernel<DIB_ACC_FMA16, 256>), QLDS_BYTES + TL_EXTRA));
     DIB_HIP_CHECK(opt_in((blur_quad_f16_norm_kernel<DIB_ACC_BITEXACT, 128>), QLDS_BYTES));
@@ -2158,31 +1883,8 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
     else if (K == 128) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb); \
     else hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 256>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);          \
   } while (0)
-      if (quad && acc_mode == DIB_ACC_FAST16 && g_fast16_pipe && tiled.n <= FLAT_MAX) {
-        // persistent, pipelined workgroups over the per-XCD lists (blur_fast16_pipe_kernel)
-        FlatBands pfb = {};
-        int longest = 0;
-        for (int x = 0; x < 8; ++x) {
-          int at = 0;
-          for (int k = 0; k < 16; ++k) {
-            pfb.begin[x][k] = k < tiled.n ? at : 0x7fffffff;
-            if (k < tiled.n) {
-              const int T = tiled.tile_begin[k + 1] - tiled.tile_begin[k];
-              at += (((x + 1) * T) >> 3) - ((x * T) >> 3);
-            }
-          }
-          pfb.begin[x][15] = at;
-          longest = at > longest ? at : longest;
-        }
-        const int slots = longest < g_fast16_pipe_slots ? longest : g_fast16_pipe_slots;
-        hipLaunchKernelGGL(blur_fast16_pipe_kernel, dim3(8 * slots), dim3(256), PIPE_LDS_BYTES, s, tiled, pfb);
-      } else if (quad && acc_mode == DIB_ACC_FAST16) {
-        const int tpw = g_fast16_tpw;
-        const dim3 gt(((gx / 8 + tpw - 1) / tpw) * 8, tiled.n);      // TPW consecutive entries of a band per workgroup
+      if (quad && acc_mode == DIB_ACC_FAST16) {
         if (flat) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, true>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
-        else if (tpw == 2) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 2>), gt, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
-        else if (tpw == 3) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 3>), gt, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
-        else if (tpw == 4) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, false, 4>), gt, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
         else hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
       } else if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_QUAD(DIB_ACC_FMA16);
       else if (quad && acc_mode == DIB_ACC_FP32 && K == 128) hipLaunchKernelGGL((blur_quad_f32acc_kernel<128>), grid, dim3(256), QLDS_BYTES, s, tiled);

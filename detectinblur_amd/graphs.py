@@ -43,7 +43,7 @@ class GraphCache(object):
     of one cache share ONE memory pool: they are replayed one at a time and their outputs are consumed in stream order before
     the next replay, so the pool holds the largest shape's activations, not the sum over the shapes (what a graph keeps for itself
     are its input and output buffers: ~0.1 GB for the detector's trunk at batch 1).  `limit`: real COCO images reach ~50 padded
-    input shapes after the transform (the grid `scratch/fill_dbs_grid.sh` fills the kernel-choice data for); a cache smaller
+    input shapes after the transform (the grid `python -m detectinblur_amd.kernel_choices --fill --shapes coco-eval` fills the kernel-choice data for); a cache smaller
     than that would evict and recapture (three forward passes each) all through an evaluation."""
 
     def __init__(self, fn, limit=64, capture_after=2):

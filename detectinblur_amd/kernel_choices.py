@@ -9,8 +9,8 @@ MIOpen picks each convolution's kernel by timing every applicable solver the fir
 at b = 8 x 800 x 1344 on a fresh machine) and remembers the result in a "user find-db"; next to it sits the user PERF-db
 (`*.udb.txt`) of a tuning run (MIOPEN_FIND_ENFORCE=SEARCH over the train step's convolutions: 100.0 -> 94.3 ms per step).
 `miopen_db/` ships both for every shape the bench, the drivers and the GPU tests meet on gfx950, for the ~50 padded batch-1 input
-shapes real COCO images reach in evaluation (scratch/fill_dbs_grid.sh) and for the padded b = 8 batch shapes of COCO training
-(800 x 800..1344 and 800..1344 x 800 in steps of 32, a few more: scratch/fill_dbs_train.sh) -- a shape without a record costs its
+shapes real COCO images reach in evaluation (`--fill --shapes coco-eval`, below) and for the padded b = 8 batch shapes of COCO training
+(800 x 800..1344 and 800..1344 x 800 in steps of 32, a few more: `--fill --shapes coco-train`) -- a shape without a record costs its
 first step 67-118 s of MIOpen's find (profiles/r5_new_batch_shapes.txt), and the find mode that skips it (MIOPEN_FIND_MODE=2)
 runs the step 18 x slower.  What MIOpen learns beyond the shipped records stays in the private copy and goes with the process: a
 user who wants to keep it sets MIOPEN_USER_DB_PATH (respected, see below).  The process works on a PRIVATE

@@ -1,0 +1,110 @@
+"""Builds profiles/r6_* from gpurun_out/prof_r6 (written by scratch/pmc_r6.sh on the GPU box): r6_bench_default.json, r6_bench_kernel_stats.csv,
+r6_bench_under_rocprof.json, r6_blur_pmc.json (the step's single launch: traffic warm / cold, averages under rocprofv3, + the tolerance
+mode's kernel), r6_fast16_pmc.txt (SQ counters by accumulation mode), r6_fast16_timeline.txt, r6_native_order.txt, r6_vrun_ubench.txt."""
+import csv, glob, json, os, shutil
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(root, "gpurun_out", "prof_r6")
+prof = os.path.join(root, "profiles")
+
+
+def counters(sub, kernel, skip):
+    out = {}
+    for f in sorted(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            v = v[skip:] if len(v) > skip else v
+            out[k] = sum(v) / len(v)
+    return out
+
+
+STEP, BLUR, FAST = "blur_step_f16_kernel<0>", "blur_quad_f16_kernel<0, 128, false>", "blur_quad_f16_kernel<3, 128, false>"
+warm, cold, fast = {}, {}, {}
+for sub in ("fetch_warm", "write_warm"):
+    warm.update(counters(sub, "blur_step_f16_kernel", 2))
+for sub in ("fetch_cold", "write_cold"):
+    cold.update(counters(sub, "blur_step_f16_kernel", 12))
+for sub in ("fetch_fast16", "write_fast16"):
+    fast.update(counters(sub, "blur_quad_f16_kernel", 4))
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
+rows = list(csv.DictReader(open(stats)))
+step = [r for r in rows if STEP in r["Name"]][0]
+blur = [r for r in rows if BLUR in r["Name"]][0]
+fast_rows = [r for r in rows if FAST in r["Name"]]
+trace = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
+tr = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace)))
+
+
+def longest_run(name):      # maximal run of back-to-back launches of ONE kernel: bench.py's roofline loops are the longest runs of each
+    best, cur = [], []
+    for _, d, n in tr:
+        if name in n:
+            cur.append(d)
+        else:
+            best, cur = (cur if len(cur) > len(best) else best), []
+    return cur if len(cur) > len(best) else best
+
+
+loop_step, loop_blur, loop_fast = longest_run(STEP), longest_run(BLUR), longest_run(FAST)
+loop_blur = loop_blur[:1040] if len(loop_blur) > 1040 else loop_blur
+fstats = sorted(glob.glob(os.path.join(src, "trace_fast16", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
+frow = [r for r in csv.DictReader(open(fstats)) if FAST in r["Name"]][0]
+shutil.copy(stats, os.path.join(prof, "r6_bench_kernel_stats.csv"))
+line = [l for l in open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines() if l.startswith("{")][-1]
+open(os.path.join(prof, "r6_bench_under_rocprof.json"), "w").write(line + "\n")
+default_line = [l for l in open(os.path.join(src, "bench_default.json")).read().strip().splitlines() if l.startswith("{")][-1]
+open(os.path.join(prof, "r6_bench_default.json"), "w").write(default_line + "\n")
+default = json.loads(default_line)
+algo = 102374400 + 8 * 32768
+tw = warm["FETCH_SIZE"] * 1024 * 2.0 + warm["WRITE_SIZE"] * 1024
+tc = cold["FETCH_SIZE"] * 1024 * 2.0 + cold["WRITE_SIZE"] * 1024
+tf = fast["FETCH_SIZE"] * 1024 * 2.0 + fast["WRITE_SIZE"] * 1024
+doc = {
+    "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --repeats 20 --no-cpu-baseline --no-train-step --no-eval-sweep --no-polling-side-run (kernel stats in r6_bench_kernel_stats.csv); PMC: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over scratch/prof_step_r5.py (the step's launch, warm and cold) and scratch/prof_modes_r6.py fast16 (the tolerance mode's kernel); scratch/pmc_r6.sh",
+    "workload": "configs[1]: batch 8 x 3x800x1333 fp16, 8 PSFs (expl 0.005, low exposure), taps per PSF [43,53,28,26,56,51,19,26]",
+    "kernel": "dib::blur_step_f16_kernel<0> (the step's single launch: 8 compacting workgroups + 6,600 blur workgroups of the default 128 x 32 tiles, bit-exact mode)",
+    "per_launch_warm": {k: warm[k] for k in sorted(warm)},
+    "per_launch_cold": {k: cold[k] for k in sorted(cold)},
+    "kernel_avg_ns": float(step["AverageNs"]), "kernel_calls": int(step["Calls"]),
+    "kernel_avg_ns_roofline_loop": sum(loop_step) / len(loop_step), "roofline_loop_calls": len(loop_step),
+    "blur_only": {"kernel": "dib::" + BLUR, "kernel_avg_ns": float(blur["AverageNs"]), "kernel_calls": int(blur["Calls"]),
+                  "kernel_avg_ns_roofline_loop": sum(loop_blur) / len(loop_blur), "roofline_loop_calls": len(loop_blur)},
+    "tolerance_mode": {"kernel": "dib::" + FAST + " (DIB_ACC_FAST16)",
+                       "kernel_avg_ns_in_bench_trace": float(fast_rows[0]["AverageNs"]) if fast_rows else None, "calls_in_bench_trace": int(fast_rows[0]["Calls"]) if fast_rows else None,
+                       "kernel_avg_ns_longest_run_in_bench_trace": (sum(loop_fast) / len(loop_fast)) if loop_fast else None,
+                       "kernel_avg_ns_own_trace": float(frow["AverageNs"]), "calls_own_trace": int(frow["Calls"]),
+                       "per_launch": {k: fast[k] for k in sorted(fast)}, "hbm_traffic_bytes_per_launch": tf,
+                       "algorithmic_bytes_per_launch": 102374400, "traffic_over_algorithmic": tf / 102374400.0,
+                       "unprofiled_same_box": default.get("roofline_tolerance")},
+    "unprofiled_same_box": {"kernel_ms": default["roofline"]["kernel_ms"], "blur_only_kernel_ms": default["roofline"]["blur_only"]["kernel_ms"],
+                            "ms_per_step": default["ms_per_step"], "value": default["value"],
+                            "note": "python bench.py (no profiler) run by the same gpurun call on the same box right before the profiled passes: profiles/r6_bench_default.json"},
+    "calibration": {"note": "scratch/ubench/ub_fetch.hip (round 1): 1 GiB read with 2-byte per-lane loads reports FETCH_SIZE = 524,293 KiB (exactly 1/2, as MI355X_MICROARCH.md states); 1 GiB of 2-byte stores reports WRITE_SIZE = 1,048,5xx KiB",
+                    "fetch_correction": 2.0, "write_correction": 1.0},
+    "hbm_traffic_bytes_per_launch": tw, "hbm_traffic_bytes_per_launch_cold": tc,
+    "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": tw / algo, "traffic_over_algorithmic_cold": tc / algo,
+}
+json.dump(doc, open(os.path.join(prof, "r6_blur_pmc.json"), "w"), indent=1)
+with open(os.path.join(prof, "r6_fast16_pmc.txt"), "w") as f:
+    f.write("SQ counters of the blur kernel on the BASELINE batch by accumulation mode, per launch (rocprofv3 --pmc, three separate passes per mode, 12 launches\n"
+            "each: scratch/pmc_modes_r6.sh + scratch/prof_modes_r6.py).  fast16 = DIB_ACC_FAST16 (vertical-run groups), fma16 = DIB_ACC_FMA16, bitexact = the default.\n"
+            "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over the launch's 26,624 waves; SQ_BUSY_CYCLES is summed over the 32 shader engines.\n\n")
+    f.write("".join(l for l in open(os.path.join(src, "pmc_modes.txt")) if l.startswith(("fast16", "fma16", "bitexact"))))
+    f.write("\nDevice time per launch, HIP graph of 20 launches replayed (scratch/t_native_ab.py; `native` = the ragged native-size batch), same box:\n")
+    f.write(open(os.path.join(src, "modes_graph.txt")).read())
+with open(os.path.join(prof, "r6_fast16_timeline.txt"), "w") as f:
+    f.write("Per-workgroup timeline of blur_quad_f16_kernel<3, 128> (DIB_ACC_FAST16) from a -DDIB_TIMELINE build (scratch/timeline_native.py, DIB_TL_MODE=fast16):\n"
+            "100 MHz wall-clock stamps per workgroup: start, wave 0's prologue done / window loads issued / first window ready / taps done, end.  The instrumented\n"
+            "build runs ~4 us longer than the shipped kernel: read the SHAPE (a workgroup's life is the SUM of its phases; docs/experiments.md, round 6).\n\n")
+    f.write(open(os.path.join(src, "tl_fast16.txt")).read())
+with open(os.path.join(prof, "r6_native_order.txt"), "w") as f:
+    f.write("Native-size ragged batch (bench.COCO_NATIVE_SIZES, 1,635 workgroups on the 1-D grid): device time of the blur by the mask of strides (32 workgroups of an\n"
+            "XCD's list) walked backwards; one process, one HIP graph of 20 launches per mask, nine interleaved rounds (scratch/t_native_masks.py).  First block: the\n"
+            "bit-exact mode (shipped: 'snake(last rev)'), second: DIB_ACC_FMA16.\n\n")
+    f.write(open(os.path.join(src, "native_masks.txt")).read())
+shutil.copy(os.path.join(src, "ub_vrun.txt"), os.path.join(prof, "r6_vrun_ubench.txt"))
+print(json.dumps({k: doc[k] for k in ("kernel_avg_ns", "kernel_avg_ns_roofline_loop", "roofline_loop_calls", "hbm_traffic_bytes_per_launch", "traffic_over_algorithmic",
+                                       "hbm_traffic_bytes_per_launch_cold", "traffic_over_algorithmic_cold")}, indent=1))
+print(json.dumps(doc["tolerance_mode"], indent=1)[:1500])

@@ -102,7 +102,7 @@ def test_every_process_gets_a_private_copy_of_the_shipped_miopen_find_db():
     assert run({"DIB_MIOPEN_DB_INPLACE": "1"})[0] == shipped
     assert run({"DIB_NO_MIOPEN_DB": "1"})[0] == "None"
     lines = sum(1 for _ in open(os.path.join(shipped, [f for f in files if f.endswith(".ufdb.txt")][0])))
-    assert lines >= 500       # the bench's, the drivers' and the tests' shapes (scratch/fill_miopen_db.sh), not only the b = 8 training ones
+    assert lines >= 500       # the bench's, the drivers' and the tests' shapes (`python -m detectinblur_amd.kernel_choices --fill --shapes bench`), not only the b = 8 training ones
 
 
 def test_every_process_reads_a_private_copy_of_the_shipped_gemm_choices():

@@ -18,12 +18,12 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # mangled-name fragment -> (max VGPRs, max SGPRs, waves per SIMD)
 BUDGET = {
-    "blur_quad_f16_kernelILi0ELi128ELb0ELi1E": (64, 80, 8),  # bit-exact, the blur alone
-    "blur_quad_f16_kernelILi2ELi128ELb0ELi1E": (64, 80, 8),  # FMA16
-    "blur_quad_f16_kernelILi0ELi128ELb1ELi1E": (64, 80, 8),  # the same two on the 1-D grid of a ragged batch
-    "blur_quad_f16_kernelILi2ELi128ELb1ELi1E": (64, 80, 8),
-    "blur_quad_f16_kernelILi3ELi128ELb0ELi1E": (64, 80, 8),  # FAST16 (vertical-run groups)
-    "blur_quad_f16_kernelILi3ELi128ELb1ELi1E": (64, 80, 8),
+    "blur_quad_f16_kernelILi0ELi128ELb0E": (64, 80, 8),  # bit-exact, the blur alone
+    "blur_quad_f16_kernelILi2ELi128ELb0E": (64, 80, 8),  # FMA16
+    "blur_quad_f16_kernelILi0ELi128ELb1E": (64, 80, 8),  # the same two on the 1-D grid of a ragged batch
+    "blur_quad_f16_kernelILi2ELi128ELb1E": (64, 80, 8),
+    "blur_quad_f16_kernelILi3ELi128ELb0E": (64, 80, 8),  # FAST16 (vertical-run groups)
+    "blur_quad_f16_kernelILi3ELi128ELb1E": (64, 80, 8),
     "blur_quad_f32acc_kernelILi128E": (64, 80, 8),       # DIB_ACC_FP32 on the default tiles
     "blur_step_f16_kernelILi0E": (64, 80, 8),            # the step's single launch: compaction + blur
     "blur_step_f16_kernelILi2E": (64, 80, 8),
