@@ -1075,13 +1075,15 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
     const i16v bb = *reinterpret_cast<const i16v *>(fb.begin[blockIdx.x & 7]);
     const int len = bb[15];
     if (entry >= len) return;
-    // Boustrophedon over the dispatcher's round robin.  A ragged batch is ONE round of workgroups, all resident at once, and the
-    // hardware deals a list's workgroups to its XCD's 32 CUs in turn: CU j runs workgroups j, j + 32, j + 64, ... of the list
-    // (measured: the per-CU tap sums of profiles/r5_native_timeline.txt are exactly those of that model).  The list is sorted by
-    // weight (heaviest image first), so dealt straight CU 0 gets the heaviest entry of EVERY stride of 32 -- and the left-over
-    // partial stride on top: 277 taps against a mean of 241 on the native-size batch.  Every other full stride is therefore
-    // walked backwards (the last full one always, so that the partial stride's workgroups, which go to CUs 0, 1, ... whatever is
-    // done, meet the lightest entries of the stride before): 259.  Which TILE a workgroup computes is all that changes.
+    // Against the dispatcher's round robin.  A ragged batch is ONE round of workgroups, all resident at once, and the hardware deals a
+    // list's workgroups to its XCD's 32 CUs in turn: CU j runs workgroups j, j + 32, j + 64, ... of the list (measured: the per-CU
+    // tap sums of profiles/r5_native_timeline.txt are exactly those of that model).  The list is sorted by weight (heaviest image
+    // first), so dealt straight CU 0 gets the heaviest entry of EVERY stride of 32 -- and a workgroup of the left-over partial stride
+    // on top: 277 taps against a mean of 241 on the native-size batch, and the CUs with a seventh workgroup are the ones that finish
+    // last whatever their taps are.  Every FULL stride is therefore walked backwards: the CUs that get the partial stride's extra
+    // workgroup (0, 1, ...) get the lightest entry of every stride before it (15.9 -> 15.1-15.3 us; walking only every other
+    // stride backwards evens the tap sums out best, 259 at most, and gains 0.1-0.3 us less: profiles/r6_native_order.txt).  Which
+    // TILE a workgroup computes is all that changes.
     {
       const int row = entry >> 5, full = len >> 5;
       if (row < full && row < 32 && ((fb.rev_mask >> row) & 1u)) entry ^= 31;
@@ -1519,7 +1521,7 @@ extern "C" void dib_debug_set_tile_order(int xcd_bands) { g_xcd_bands = xcd_band
 // compare the two).
 static int g_flat_grid = !(getenv("DIB_FLAT_GRID") && getenv("DIB_FLAT_GRID")[0] == '0');
 extern "C" void dib_debug_set_flat_grid(int on) { g_flat_grid = on ? 1 : 0; }
-// ... and on it, every other stride of 32 workgroups of an XCD's list walked backwards (default; 0 in A/B runs)
+// ... and on it, every full stride of 32 workgroups of an XCD's list walked backwards (default; 0 in A/B runs)
 static int g_flat_snake = !(getenv("DIB_FLAT_SNAKE") && getenv("DIB_FLAT_SNAKE")[0] == '0');
 extern "C" void dib_debug_set_flat_snake(int on) { g_flat_snake = on ? 1 : 0; }
 static int g_flat_mask = -1;      // experiments: an explicit stride mask
@@ -1868,11 +1870,8 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
             longest = at > longest ? at : longest;
           }
           grid = dim3(8 * longest, 1);
-          // strides walked backwards: every other one, the last full one always (the kernel's comment); A/B runs set the mask
-          const int full = (longest >> 5) > 32 ? 32 : (longest >> 5);
-          unsigned snake = 0;
-          for (int r = full - 1; r >= 0; r -= 2) snake |= 1u << r;
-          fb.rev_mask = g_flat_mask >= 0 ? (unsigned)g_flat_mask : (g_flat_snake ? snake : 0u);
+          // strides walked backwards: all (the kernel's comment; only FULL strides are looked at); A/B runs set the mask
+          fb.rev_mask = g_flat_mask >= 0 ? (unsigned)g_flat_mask : (g_flat_snake ? 0xffffffffu : 0u);
         }
       }
 #define DIB_LAUNCH_QUAD(ACCM)                                                                                             \

@@ -163,7 +163,7 @@ struct StepSync {
 // x of image 0, then band x of image 1, ...: begin[x][k] = entry at which image k starts (INT_MAX for k >= n), begin[x][15] =
 // the list's length.  One 64-byte scalar load per workgroup; at most FLAT_MAX images per launch.
 constexpr int FLAT_MAX = 15;
-struct FlatBands { int begin[8][16]; unsigned rev_mask; };     // rev_mask bit r: stride r (32 workgroups) of every list is walked backwards
+struct FlatBands { int begin[8][16]; unsigned rev_mask; };     // rev_mask bit r: full stride r (32 workgroups) of every list is walked backwards
 
 struct BlurBatch {
   ImageDesc img[MAX_BATCH];
