@@ -102,7 +102,7 @@ with open(os.path.join(prof, "r6_fast16_timeline.txt"), "w") as f:
 with open(os.path.join(prof, "r6_native_order.txt"), "w") as f:
     f.write("Native-size ragged batch (bench.COCO_NATIVE_SIZES, 1,635 workgroups on the 1-D grid): device time of the blur by the mask of strides (32 workgroups of an\n"
             "XCD's list) walked backwards; one process, one HIP graph of 20 launches per mask, nine interleaved rounds (scratch/t_native_masks.py).  First block: the\n"
-            "bit-exact mode (shipped: 'snake(last rev)'), second: DIB_ACC_FMA16.\n\n")
+            "bit-exact mode (shipped: 'all rev'), second: DIB_ACC_FMA16 (shipped for the tolerance modes: 'none').\n\n")
     f.write(open(os.path.join(src, "native_masks.txt")).read())
 shutil.copy(os.path.join(src, "ub_vrun.txt"), os.path.join(prof, "r6_vrun_ubench.txt"))
 print(json.dumps({k: doc[k] for k in ("kernel_avg_ns", "kernel_avg_ns_roofline_loop", "roofline_loop_calls", "hbm_traffic_bytes_per_launch", "traffic_over_algorithmic",

@@ -12,7 +12,7 @@ idx = sorted(range(8), key=lambda k: -dicts[k]["psf_taps"])
 native = [torch.rand(3, h, w, generator=torch.Generator().manual_seed(31 + i)).half().to(dev) for i, (h, w) in enumerate(bench.COCO_NATIVE_SIZES)]
 ordered = [native[k] for k in idx]
 l = _lib.lib(); l.dib_debug_set_flat_mask.argtypes = [ctypes.c_int]
-masks = {"none": 0, "all rev (shipped)": 0b1111111, "snake(last rev)": 0b0101010, "snake(first rev)": 0b1010101, "first4 rev": 0b0001111, "last3 rev": 0b1110000, "first2 rev": 0b0000011}
+masks = {"none": 0, "all rev": 0b1111111, "snake(last rev)": 0b0101010, "snake(first rev)": 0b1010101, "first4 rev": 0b0001111, "last3 rev": 0b1110000, "first2 rev": 0b0000011}
 graphs = {}
 for name, m in masks.items():
     l.dib_debug_set_flat_mask(m)
