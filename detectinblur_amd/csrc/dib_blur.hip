@@ -767,17 +767,11 @@ struct NormArgs {
 // LDS byte address of a __shared__ array (the tile function takes the integer: with a generic pointer to LDS handed through the
 // call hipcc 7.2 emitted an illegal null test in some instantiations: "V_CMP_NE_U32_e32 0, $src_shared_base")
 __device__ __forceinline__ unsigned lds_addr(unsigned *shared) { return (unsigned)(size_t)(__attribute__((address_space(3))) char *)shared; }
-#ifdef DIB_EXP_PERSIST
-extern __device__ unsigned dib_persist_ctr[8 * 32];
-__device__ __forceinline__ unsigned *persist_ctr() { return dib_persist_ctr + 32 * (blockIdx.x & 7); }
-#else
-__device__ __forceinline__ unsigned *persist_ctr() { return nullptr; }
-#endif
-template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait, bool NORM = false, bool PERSIST = false>
+template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait, bool NORM = false>
 __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
                                                    const unsigned lds0, const int wave, const int early = 0, const int nsegs0 = 0,
                                                    const uint4 seg0 = uint4{0, 0, 0, 0}, const Wait wait_tables = Wait(),
-                                                   const NormArgs *na = nullptr, const int img = 0, unsigned *next_ctr = nullptr) {
+                                                   const NormArgs *na = nullptr, const int img = 0) {
 #pragma clang fp contract(off)
   constexpr int GQ = QGeom<L>::GQ;            // LDS rows a wave fills (11; large window: 15)
   constexpr int QPITCH = QGeom<L>::PITCH, QUAD_PITCH = QGeom<L>::PITCH_EL, LROWS = QGeom<L>::ROWS;   // shadow the standard geometry's constants
@@ -957,13 +951,6 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       *(__attribute__((address_space(3))) unsigned long long *)(size_t)(lds0 + QGeom<false>::BYTES + 16) = __builtin_amdgcn_s_memrealtime();
 #endif
     if constexpr (STEP) { if (sg == 0 && (nsegs >> 30)) wait_tables(); }
-#ifdef DIB_PERSIST_PRIO
-    if constexpr (PERSIST) __builtin_amdgcn_s_setprio(2);      // tapping waves before filling ones (what age gives the plain kernel's workgroups)
-#endif
-    unsigned v_next = 0;           // PERSIST: the workgroup's NEXT tile, asked for here, under the last window's tap loop; lives inside this iteration only
-    if constexpr (PERSIST) {
-      if (sg == nsegs - 1 && wave == 0 && fresh_lane() == 0) v_next = __hip_atomic_fetch_add(persist_ctr(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     const int tl = fresh_lane();
     const unsigned lane_addr = lds0 + (unsigned)((wave * 8 + (tl >> 5) * 4) * QPITCH + (tl & 31) * 8);
     if constexpr (ACC == DIB_ACC_FP32) {
@@ -983,17 +970,10 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       if (W - x0f() <= 64) tap_loop_quad<ACC == DIB_ACC_FMA16, true, L>(acc, ltaps, w.t0, w.n, lane_addr);
       else tap_loop_quad<ACC == DIB_ACC_FMA16, false, L>(acc, ltaps, w.t0, w.n, lane_addr);
     }
-    if constexpr (PERSIST) {
-      if (sg == nsegs - 1 && wave == 0 && fresh_lane() == 0) *(__attribute__((address_space(3))) unsigned *)(size_t)(lds0 + QGeom<false>::BYTES) = v_next;
-    }
   }
   if constexpr (ACC == DIB_ACC_FP32) {      // the one rounding of this mode
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = h2{(_Float16)acc32[2 * i], (_Float16)acc32[2 * i + 1]};
-  }
-  if constexpr (PERSIST) {
-    if (nsegs == 0 && wave == 0 && fresh_lane() == 0)
-      *(__attribute__((address_space(3))) unsigned *)(size_t)(lds0 + QGeom<false>::BYTES) = __hip_atomic_fetch_add(persist_ctr(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #ifdef DIB_TIMELINE
   if (!L && !STEP && wave == 0 && fresh_lane() == 0)
@@ -1045,39 +1025,6 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
       const i4v rs = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa2), __builtin_amdgcn_readfirstlane((int)(unsigned)(pa2 >> 32)) & 0xffff,
                       H * W * 2, 0x00020000};
       int so = 0;
-#if defined(DIB_EXP_ST) && DIB_EXP_ST == 1      // timing only: same instructions, every store into one 256 KB stretch (no HBM write-back)
-      const unsigned base1 = base & 0x3fffeu;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        asm volatile("buffer_store_short %0, %2, %3, %4 offen\n\t"
-                     "buffer_store_short_d16_hi %0, %2, %3, %4 offen offset:64\n\t"
-                     "buffer_store_short %1, %2, %3, %4 offen offset:128\n\t"
-                     "buffer_store_short_d16_hi %1, %2, %3, %4 offen offset:192"
-                     :: "v"(acc[2 * i]), "v"(acc[2 * i + 1]), "v"(base1), "s"(rs), "s"(so) : "memory");
-        so += w2;
-      }
-      return;
-#elif defined(DIB_EXP_ST) && DIB_EXP_ST == 2    // timing only: the same bytes as 8 dword stores per wave (128 contiguous bytes per row and instruction)
-      const unsigned base2 = ((unsigned)(yl * w2 + x0 * 2) & ~3u) + (unsigned)(sl & 31) * 4u;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        asm volatile("buffer_store_dword %0, %2, %3, %4 offen\n\t"
-                     "buffer_store_dword %1, %2, %3, %4 offen offset:128"
-                     :: "v"(acc[2 * i]), "v"(acc[2 * i + 1]), "v"(base2), "s"(rs), "s"(so) : "memory");
-        so += w2;
-      }
-      return;
-#elif defined(DIB_EXP_ST) && DIB_EXP_ST == 3    // timing only: 4 dwordx2 stores per wave (256 contiguous bytes per row and instruction)
-      const unsigned base3 = ((unsigned)(yl * w2 + x0 * 2) & ~3u) + (unsigned)(sl & 31) * 8u;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        typedef unsigned u2v __attribute__((ext_vector_type(2)));
-        const u2v pr = {__builtin_bit_cast(unsigned, acc[2 * i]), __builtin_bit_cast(unsigned, acc[2 * i + 1])};
-        asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(pr), "v"(base3), "s"(rs), "s"(so) : "memory");
-        so += w2;
-      }
-      return;
-#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         asm volatile("buffer_store_short %0, %2, %3, %4 offen\n\t"
@@ -1186,66 +1133,6 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
   }
 #endif
 }
-
-#ifdef DIB_EXP_PERSIST
-// Experiment: one workgroup per SLOT (8 per CU), each walking its XCD's tile list: first entry = its index in the XCD, further
-// entries from a per-XCD counter (asked for under the last tap loop of the tile before).  dib_persist_ctr: 32 words per XCD
-// {fetch, done}; the last workgroup of a list to leave zeroes both.
-__device__ unsigned dib_persist_ctr[8 * 32];
-constexpr int PERSIST_WG = 256;      // workgroups per XCD list (32 CUs x 8)
-template <int ACC, int KC>
-__global__ __launch_bounds__(256, 8) void blur_quad_f16_persist_kernel(BlurBatch batch, FlatBands fb) {
-  constexpr int K = KC;
-  extern __shared__ unsigned nlds[];
-  int entry = blockIdx.x >> 3;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // the one value kept across the tiles (threadIdx.x itself must not be)
-  for (;;) {
-    // everything a tile needs is formed again from the block index (opaque copies: nothing loop-invariant may be hoisted and
-    // kept alive across the tile function, which has no scalar register to spare)
-    int x = blockIdx.x & 7;
-    asm volatile("" : "+s"(x));
-    typedef int i16v __attribute__((ext_vector_type(16)));
-    const i16v bb = *reinterpret_cast<const i16v *>(fb.begin[x]);
-    const int len = bb[15];
-    if (entry >= len) break;
-    int start = bb[0], img_i = 0;
-#pragma unroll
-    for (int k = 1; k < FLAT_MAX; ++k) {
-      const bool ge = entry >= bb[k];
-      img_i += ge ? 1 : 0;
-      start = ge ? bb[k] : start;
-    }
-    const ImageDesc d = batch.img[img_i];
-    asm volatile("" ::"s"(d.in), "s"(d.out), "s"(d.C), "s"(d.H), "s"(d.W), "s"(d.table), "s"(d.tiles_x), "s"(d.tiles_y),
-                 "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab));
-    const int per_ch = d.tiles_x * d.tiles_y;
-    int local;
-    band_entry(d.C * per_ch, x, entry - start, local);
-    const int ch = magic_div(local, d.inv_per_ch);
-    local -= ch * per_ch;
-    const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-    blur_quad_tile_f16<ACC, false, false, NoWait, false, true>(d, d.tab, K, ch, tx, ty, lds_addr(nlds), wave);
-    __syncthreads();
-#ifdef DIB_PERSIST_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    entry = PERSIST_WG + __builtin_amdgcn_readfirstlane((int)*(volatile unsigned *)(nlds + QLDS_BYTES / 4));
-  }
-  int lane0;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane0));
-  if (wave == 0 && lane0 == 0) {
-    unsigned *my = dib_persist_ctr + 32 * (blockIdx.x & 7);
-    const unsigned old = __hip_atomic_fetch_add(my + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == PERSIST_WG - 1) {
-      __hip_atomic_store(my, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(my + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-template __global__ void blur_quad_f16_persist_kernel<DIB_ACC_BITEXACT, 128>(BlurBatch, FlatBands);
-template __global__ void blur_quad_f16_persist_kernel<DIB_ACC_FMA16, 128>(BlurBatch, FlatBands);
-template __global__ void blur_quad_f16_persist_kernel<DIB_ACC_FAST16, 128>(BlurBatch, FlatBands);
-#endif
 
 // =============================================================================================
 // The blur STEP as ONE launch (dib_blur_step: tap compaction + blur; reference models/blur_functions.py:92-100).
@@ -1989,28 +1876,6 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
           fb.rev_mask = g_flat_mask >= 0 ? (unsigned)g_flat_mask : (g_flat_snake && acc_mode == DIB_ACC_BITEXACT ? 0xffffffffu : 0u);
         }
       }
-#ifdef DIB_EXP_PERSIST
-      static const int persist = getenv("DIB_PERSIST") ? atoi(getenv("DIB_PERSIST")) : 0;
-      if (persist && quad && !large && K == 128 && tiled.n <= FLAT_MAX && acc_mode != DIB_ACC_FP32) {
-        for (int x = 0; x < 8; ++x) {
-          int at = 0;
-          for (int k = 0; k < 16; ++k) {
-            fb.begin[x][k] = k < tiled.n ? at : 0x7fffffff;
-            if (k < tiled.n) {
-              const int T = tiled.tile_begin[k + 1] - tiled.tile_begin[k];
-              at += (((x + 1) * T) >> 3) - ((x * T) >> 3);
-            }
-          }
-          fb.begin[x][15] = at;
-        }
-        const dim3 pg(8 * PERSIST_WG);
-        if (acc_mode == DIB_ACC_FAST16) hipLaunchKernelGGL((blur_quad_f16_persist_kernel<DIB_ACC_FAST16, 128>), pg, dim3(256), QLDS_BYTES + 16, s, tiled, fb);
-        else if (acc_mode == DIB_ACC_FMA16) hipLaunchKernelGGL((blur_quad_f16_persist_kernel<DIB_ACC_FMA16, 128>), pg, dim3(256), QLDS_BYTES + 16, s, tiled, fb);
-        else hipLaunchKernelGGL((blur_quad_f16_persist_kernel<DIB_ACC_BITEXACT, 128>), pg, dim3(256), QLDS_BYTES + 16, s, tiled, fb);
-        DIB_HIP_CHECK(hipGetLastError());
-        continue;
-      }
-#endif
 #define DIB_LAUNCH_QUAD(ACCM)                                                                                             \
   do {                                                                                                                   \
     if (large && K == 128) hipLaunchKernelGGL((blur_quad_large_f16_kernel<ACCM, 128>), grid, dim3(256), QGeom<true>::BYTES, s, tiled); \
