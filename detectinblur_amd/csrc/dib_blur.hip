@@ -65,13 +65,8 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int TILE_W = 256;
 constexpr int PQ = WIN_PITCH;         // LDS row pitch in 8-byte words (96)
-#ifdef DIB_EXP_TALL     // experiment: 128 x 64 tiles on 8-wave workgroups, four per CU (only blur_quad_f16_kernel is valid in such a build)
-constexpr int TH = 64;
-constexpr int LROWS = 80;             // 76 needed; 10 per wave
-#else
 constexpr int TH = 32;                // tile rows
 constexpr int LROWS = TH + SEG_ROWS;  // LDS rows per window (44)
-#endif
 constexpr int LDS_BYTES = LROWS * PQ * 8;  // 33,792 B: four workgroups per CU
 static_assert(WIN_PITCH * 8 == 768, "the asm below hard-codes the LDS row pitch");
 
@@ -263,11 +258,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *img_bas
   return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, H * W * 2, 0x00020000);
 }
 
-#ifdef DIB_EXP_TALL
-constexpr int NW = 8;
-#else
 constexpr int NW = 4;                       // waves per workgroup
-#endif
 constexpr int R = TH / NW;                  // rows per lane (8)
 constexpr int G = (LROWS + NW - 1) / NW;    // LDS rows a wave fills (11): all of them in ONE batch of loads
 
@@ -519,18 +510,12 @@ static_assert(LROWS % NW == 0, "every wave fills the same number of window rows"
 template <bool L> struct QGeom {
   static constexpr int PITCH_EL = L ? QUAD_PITCH_L : QUAD_PITCH;   // elements per LDS row
   static constexpr int PITCH = PITCH_EL * 8;                       // bytes per LDS row
-#ifdef DIB_EXP_TALL
-  static constexpr int ROWS = L ? 88 : LROWS;
-#else
   static constexpr int ROWS = TH + (L ? SEG_ROWS_L : SEG_ROWS);    // LDS rows
-#endif
   static constexpr int GQ = ROWS / NW;                             // rows a wave fills
   static constexpr int BYTES = ROWS * PITCH;
 };
 static_assert(QGeom<false>::PITCH == QPITCH && QGeom<false>::ROWS == LROWS && QGeom<false>::BYTES == QLDS_BYTES, "standard geometry");
-#ifndef DIB_EXP_TALL
 static_assert(QGeom<true>::PITCH == 768 && QGeom<true>::ROWS % NW == 0 && QGeom<true>::BYTES == 39936, "the asm below hard-codes the large window's row pitch");
-#endif
 
 // Tap loop of the quad shape: 4 x 8-byte reads per tap, rows i = 0..3 land in v[base+2i : base+2i+1] = the operands of
 // accumulators 2i (columns j, j+32) and 2i+1 (columns j+64, j+96); the LDS address is one v_mad_u32_u16 (low 16 bits of
@@ -1081,7 +1066,7 @@ constexpr int TL_WORD = QLDS_BYTES / 4;
 // FLAT (ragged batches, dib_common.h: FlatBands): a 1-D grid of exactly the working workgroups; the image comes from one more
 // scalar load (the XCD list's 16 entry offsets) in front of the descriptor's.
 template <int ACC, int KC, bool FLAT = false>
-__global__ __launch_bounds__(64 * NW, 8) void blur_quad_f16_kernel(BlurBatch batch, FlatBands fb) {
+__global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, FlatBands fb) {
   constexpr int K = KC;
   extern __shared__ unsigned nlds[];
   int img_i = blockIdx.y, entry = blockIdx.x >> 3;
@@ -1895,13 +1880,13 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
   do {                                                                                                                   \
     if (large && K == 128) hipLaunchKernelGGL((blur_quad_large_f16_kernel<ACCM, 128>), grid, dim3(256), QGeom<true>::BYTES, s, tiled); \
     else if (large) hipLaunchKernelGGL((blur_quad_large_f16_kernel<ACCM, 256>), grid, dim3(256), QGeom<true>::BYTES, s, tiled);       \
-    else if (flat) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128, true>), grid, dim3(64 * NW), QLDS_BYTES + TL_EXTRA, s, tiled, fb); \
-    else if (K == 128) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128>), grid, dim3(64 * NW), QLDS_BYTES + TL_EXTRA, s, tiled, fb); \
+    else if (flat) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128, true>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb); \
+    else if (K == 128) hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb); \
     else hipLaunchKernelGGL((blur_quad_f16_kernel<ACCM, 256>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);          \
   } while (0)
       if (quad && acc_mode == DIB_ACC_FAST16) {
-        if (flat) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, true>), grid, dim3(64 * NW), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
-        else hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128>), grid, dim3(64 * NW), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
+        if (flat) hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128, true>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
+        else hipLaunchKernelGGL((blur_quad_f16_kernel<DIB_ACC_FAST16, 128>), grid, dim3(256), QLDS_BYTES + TL_EXTRA, s, tiled, fb);
       } else if (quad && acc_mode == DIB_ACC_FMA16) DIB_LAUNCH_QUAD(DIB_ACC_FMA16);
       else if (quad && acc_mode == DIB_ACC_FP32 && K == 128) hipLaunchKernelGGL((blur_quad_f32acc_kernel<128>), grid, dim3(256), QLDS_BYTES, s, tiled);
       else if (quad && acc_mode == DIB_ACC_FP32) hipLaunchKernelGGL((blur_quad_f32acc_kernel<256>), grid, dim3(256), QLDS_BYTES, s, tiled);
