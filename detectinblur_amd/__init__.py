@@ -12,4 +12,11 @@ __version__ = "0.1.0"
 # Shipped kernel-choice data for MIOpen / TunableOp is an explicit opt-in now (round-4 review: importing a drop-in library must
 # not export MIOPEN_* / PYTORCH_TUNABLEOP_* into its caller's environment): the drivers and bench.py call
 # `detectinblur_amd.use_shipped_kernel_choices()` before their first convolution; see kernel_choices.py.
-from .kernel_choices import report as kernel_choices_report, use_shipped_kernel_choices  # noqa: E402,F401
+# (resolved on first use, so that `python -m detectinblur_amd.kernel_choices` runs ONE copy of that module)
+
+
+def __getattr__(name):
+    if name in ("kernel_choices_report", "use_shipped_kernel_choices"):
+        from . import kernel_choices
+        return kernel_choices.report if name == "kernel_choices_report" else kernel_choices.use_shipped_kernel_choices
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
