@@ -97,7 +97,9 @@ with open(os.path.join(prof, "r6_fast16_pmc.txt"), "w") as f:
 with open(os.path.join(prof, "r6_fast16_timeline.txt"), "w") as f:
     f.write("Per-workgroup timeline of blur_quad_f16_kernel<3, 128> (DIB_ACC_FAST16) from a -DDIB_TIMELINE build (scratch/timeline_native.py, DIB_TL_MODE=fast16):\n"
             "100 MHz wall-clock stamps per workgroup: start, wave 0's prologue done / window loads issued / first window ready / taps done, end.  The instrumented\n"
-            "build runs ~4 us longer than the shipped kernel: read the SHAPE (a workgroup's life is the SUM of its phases; docs/experiments.md, round 6).\n\n")
+            "build runs ~4 us longer than the shipped kernel: read the SHAPE (a workgroup's life is the SUM of its phases; docs/experiments.md, round 6).\n"
+            "The native launches below ran with every full stride of the 1-D grid walked backwards (what the bit-exact mode ships; the tolerance modes now keep the\n"
+            "straight order, 0.3 us faster: r6_native_order.txt).\n\n")
     f.write(open(os.path.join(src, "tl_fast16.txt")).read())
 with open(os.path.join(prof, "r6_native_order.txt"), "w") as f:
     f.write("Native-size ragged batch (bench.COCO_NATIVE_SIZES, 1,635 workgroups on the 1-D grid): device time of the blur by the mask of strides (32 workgroups of an\n"
