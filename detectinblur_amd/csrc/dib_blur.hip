@@ -74,6 +74,27 @@ static_assert(WIN_PITCH * 8 == 768, "the asm below hard-codes the LDS row pitch"
 // 2 x 32-bit vector operand of an inline-asm "=v" output to the same register.
 typedef unsigned long long u2;
 
+// ---- -DDIB_PORTABLE_TAPS: the tap loops and the step's wait as plain C++ ---------------------------------------------------------
+// The hand-written loops below name vector and scalar registers and lean on what hipcc 7.2 does around them; a compiler that
+// allocates differently turns tests/test_kernel_resources.py red.  `make portable` (csrc/Makefile) builds libdib_hip_portable.so
+// with every asm loop replaced by the C++ restatement next to it: the SAME operations on the same operands in the same order
+// (bit-identical results -- the GPU suite runs green on it: DIB_HIP_LIB=.../libdib_hip_portable.so python -m pytest tests -m gpu),
+// scheduled by the compiler, slower and outside the register budget.  A way to keep working, not a product path.
+#ifdef DIB_PORTABLE_TAPS
+typedef unsigned uvec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uvec2 lds_b64(unsigned addr) { return *(const __attribute__((address_space(3))) uvec2 *)(size_t)addr; }
+__device__ __forceinline__ unsigned lds_b32(unsigned addr) { return *(const __attribute__((address_space(3))) unsigned *)(size_t)addr; }
+__device__ __forceinline__ _Float16 half_of(unsigned bits) { return __builtin_bit_cast(_Float16, (unsigned short)(bits & 0xffffu)); }
+// one tap on one packed register: the reference's multiply, rounded, then its add, rounded -- or (FUSED) one fused multiply-add
+template <bool FUSED>
+__device__ __forceinline__ h2 tap_pk(h2 acc, unsigned p_bits, _Float16 w) {
+#pragma clang fp contract(off)
+  const h2 p = __builtin_bit_cast(h2, p_bits);
+  if constexpr (FUSED) return h2{(_Float16)__builtin_fmaf16(w, p.x, acc.x), (_Float16)__builtin_fmaf16(w, p.y, acc.y)};
+  else { const h2 t = h2{(_Float16)(w * p.x), (_Float16)(w * p.y)}; return h2{(_Float16)(acc.x + t.x), (_Float16)(acc.y + t.y)}; }
+}
+#endif
+
 // ---- the tap loop, hand-written ------------------------------------------------------------------
 // Left to hipcc the loop serialises (it merges the 8-byte LDS reads into half-rate ds_read2_b64,
 // sinks the scalar tap load to its first use and waits right behind every access), and stitching
@@ -155,6 +176,22 @@ typedef unsigned long long u2;
 // to such a register, but not before this asm's.
 template <bool FUSED, bool HALF>
 __device__ __forceinline__ void tap_loop_r8(h2 (&acc)[8][2], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+#ifdef DIB_PORTABLE_TAPS
+  {
+    const unsigned *lt = reinterpret_cast<const unsigned *>(ltaps);
+    for (int t = t0; t < t0 + n; ++t) {
+      const unsigned word = lt[t];
+      const _Float16 w = half_of(word >> 16);
+      const unsigned at = lane_addr + (word & 0xffffu);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (HALF) acc[i][0] = tap_pk<FUSED>(acc[i][0], lds_b32(at + 768u * i), w);
+        else { const uvec2 e = lds_b64(at + 768u * i); acc[i][0] = tap_pk<FUSED>(acc[i][0], e.x, w); acc[i][1] = tap_pk<FUSED>(acc[i][1], e.y, w); }
+      }
+    }
+    return;
+  }
+#endif
   // cnt = taps left minus one: the borrow of its decrement ends the loop (n >= 1 in every segment)
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
   unsigned sA, sB, sC, st;
@@ -570,6 +607,23 @@ static_assert(QGeom<true>::PITCH == 768 && QGeom<true>::ROWS % NW == 0 && QGeom<
 #define DIBQ_NEXT(LABEL) "s_sub_u32 %9, %9, 1\n\ts_cbranch_scc1 " LABEL "\n\t"
 template <bool FUSED, bool HALF, bool L = false>
 __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+#ifdef DIB_PORTABLE_TAPS
+  {
+    constexpr unsigned PITCH_B = L ? 768u : 448u;
+    const unsigned *lt = reinterpret_cast<const unsigned *>(ltaps);
+    for (int t = t0; t < t0 + n; ++t) {
+      const unsigned word = lt[t];
+      const _Float16 w = half_of(word >> 16);
+      const unsigned at = lane_addr + (word & 0xffffu);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (HALF) acc[2 * i] = tap_pk<FUSED>(acc[2 * i], lds_b32(at + PITCH_B * i), w);
+        else { const uvec2 e = lds_b64(at + PITCH_B * i); acc[2 * i] = tap_pk<FUSED>(acc[2 * i], e.x, w); acc[2 * i + 1] = tap_pk<FUSED>(acc[2 * i + 1], e.y, w); }
+      }
+    }
+    return;
+  }
+#endif
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
   unsigned a[8];
 #pragma unroll
@@ -636,6 +690,29 @@ __device__ __forceinline__ void tap_loop_quad(h2 (&acc)[8], unsigned long long l
 #define DIBF_NEXT(LABEL) "s_sub_u32 %17, %17, 1\n\ts_cbranch_scc1 " LABEL "\n\t"
 template <bool HALF, bool L>
 __device__ __forceinline__ void tap_loop_quad_fp32(float (&acc)[16], unsigned long long ltaps, int t0, int n, unsigned lane_addr) {
+#ifdef DIB_PORTABLE_TAPS
+  {
+    constexpr unsigned PITCH_B = L ? 768u : 448u;
+    const unsigned *lt = reinterpret_cast<const unsigned *>(ltaps);
+    for (int t = t0; t < t0 + n; ++t) {
+      const unsigned word = lt[t];
+      const float w = (float)half_of(word >> 16);
+      const unsigned at = lane_addr + (word & 0xffffu);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {       // the product of two fp16 values is exact in fp32: fused == unfused
+        uvec2 e;
+        if constexpr (HALF) { e.x = lds_b32(at + PITCH_B * i); e.y = 0; } else e = lds_b64(at + PITCH_B * i);
+        acc[4 * i] = __builtin_fmaf(w, (float)half_of(e.x), acc[4 * i]);
+        acc[4 * i + 1] = __builtin_fmaf(w, (float)half_of(e.x >> 16), acc[4 * i + 1]);
+        if constexpr (!HALF) {
+          acc[4 * i + 2] = __builtin_fmaf(w, (float)half_of(e.y), acc[4 * i + 2]);
+          acc[4 * i + 3] = __builtin_fmaf(w, (float)half_of(e.y >> 16), acc[4 * i + 3]);
+        }
+      }
+    }
+    return;
+  }
+#endif
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(t0 * 4), cnt = (unsigned)__builtin_amdgcn_readfirstlane(n - 1);
 #define DIB_RF_ASM(RD, ARITH_X, ARITH_Y) \
   asm volatile( \
@@ -722,6 +799,36 @@ __device__ __forceinline__ void tap_loop_quad_fp32(float (&acc)[16], unsigned lo
   "s_branch Lvr_c1" P "%=\n\t"
 template <bool HALF>
 __device__ __forceinline__ void tap_loop_quad_vrun(h2 (&acc)[8], unsigned long long vgroups, int g0, unsigned lane_addr) {
+#ifdef DIB_PORTABLE_TAPS
+  {
+    const uint4 *rec = reinterpret_cast<const uint4 *>(vgroups) + g0;
+    uint4 r = rec[0];
+    unsigned off = r.w & 0xffffu, code = (r.w >> 16) & 7u;      // the first record names its own group
+    for (int g = 0;; ++g) {
+      const int n = (int)code + 1;
+      uvec2 row[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        row[k] = uvec2{0u, 0u};
+        if (k < n + 3) { if constexpr (HALF) row[k].x = lds_b32(lane_addr + off + 448u * k); else row[k] = lds_b64(lane_addr + off + 448u * k); }
+      }
+#pragma unroll
+      for (int j = 3; j >= 0; --j) {         // taps from the group's highest index down (the asm's order, the oracle's tap_order_vruns)
+        if (j >= n) continue;
+        const _Float16 w = half_of((j < 2 ? r.y : r.z) >> (16 * (j & 1)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[2 * i] = tap_pk<true>(acc[2 * i], row[j + i].x, w);
+          if constexpr (!HALF) acc[2 * i + 1] = tap_pk<true>(acc[2 * i + 1], row[j + i].y, w);
+        }
+      }
+      off = r.x & 0xffffu; code = (r.x >> 16) & 7u;
+      if (code == 4u) break;
+      r = rec[g + 1];
+    }
+    return;
+  }
+#endif
   unsigned toff = (unsigned)__builtin_amdgcn_readfirstlane(g0 * 16);
   unsigned a[8];
 #pragma unroll
@@ -1180,6 +1287,20 @@ struct StepWait {
   //   through the code object's `dib_status_word`) and ends; dib_blur_step reports it on its next call (include/dib.h).
   __device__ __forceinline__ void operator()() const {
     static_assert(STEP_REPLICA_WORDS * 4 == 128, "the shift below");
+#ifdef DIB_PORTABLE_TAPS
+    {
+      const uvec2 sp = lds_b64(lds_words), tb = lds_b64(lds_words + 8);
+      const unsigned xcc = __builtin_amdgcn_s_getreg((2 << 11) | 20);       // HW_REG_XCC_ID[2:0]
+      const unsigned *ctr = reinterpret_cast<const unsigned *>((((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)sp.y) << 32) |
+                                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)sp.x)) + 128ull * xcc);
+      const unsigned target = (unsigned)__builtin_amdgcn_readfirstlane((int)tb.x), budget = (unsigned)__builtin_amdgcn_readfirstlane((int)tb.y);
+      for (unsigned spins = 0;; ++spins) {
+        if ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return;
+        if (spins >= budget) report_and_exit(DIB_STATUS_HANDOFF, target);
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+#endif
     asm volatile(
         "v_mov_b32 v48, %0\n\t"
         "ds_read_b64 v[46:47], v48\n\t"
