@@ -874,7 +874,7 @@ struct NormArgs {
 // LDS byte address of a __shared__ array (the tile function takes the integer: with a generic pointer to LDS handed through the
 // call hipcc 7.2 emitted an illegal null test in some instantiations: "V_CMP_NE_U32_e32 0, $src_shared_base")
 __device__ __forceinline__ unsigned lds_addr(unsigned *shared) { return (unsigned)(size_t)(__attribute__((address_space(3))) char *)shared; }
-template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait, bool NORM = false, bool HDR = false>
+template <int ACC, bool L = false, bool STEP = false, typename Wait = NoWait, bool NORM = false>
 __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int *__restrict__ tab, int K, int ch, int tx, int ty,
                                                    const unsigned lds0, const int wave, const int early = 0, const int nsegs0 = 0,
                                                    const uint4 seg0 = uint4{0, 0, 0, 0}, const Wait wait_tables = Wait(),
@@ -894,12 +894,6 @@ __device__ __forceinline__ void blur_quad_tile_f16(const ImageDesc &d, const int
   if (STEP && early) {
     nsegs = nsegs0 | 1 << 30;       // bit 30: "wait for the tables in front of the first tap loop" (no register of its own)
     seg = seg0;
-  } else if constexpr (HDR) {       // experiment: the caller fetched header word 5 (`early`), the segment count and the first segment
-    nsegs = nsegs0;
-    seg = seg0;
-    const unsigned kw = (unsigned)early >> 16;
-    if ((kw & 1u) != (L ? 1u : 0u)) report_and_exit(DIB_STATUS_GEOMETRY, (unsigned)early);
-    if constexpr (ACC == DIB_ACC_FAST16) use_vruns = (int)(kw >> 1) & 1;
   } else {
     // header words 4..7 in one request (cmax, K | geometry << 16, sum, segment count) next to the first segment
     unsigned __int128 r, hd;
@@ -1246,37 +1240,6 @@ __global__ __launch_bounds__(256, 8) void blur_quad_f16_kernel(BlurBatch batch, 
   }
 #endif
 }
-
-#ifdef DIB_EXP_PRELOAD
-// Experiment (timing only: the table index is taken to be the image index): the table base arrives in PRELOADED scalar registers
-// (-mllvm -amdgpu-kernarg-preload-count=2), so the header + first-segment request does not wait for the descriptor: the prologue's
-// two dependent scalar round trips become one.
-template <int ACC>
-__global__ __launch_bounds__(256, 8) void blur_quad_f16_pre_kernel(const int *tables_base, BlurBatch batch) {
-  constexpr int K = 128;
-  extern __shared__ unsigned nlds[];
-  const int img_i = blockIdx.y, entry = blockIdx.x >> 3;
-  const int *tab = tables_base + (size_t)img_i * table_words(K);
-  const uint4 *segs = reinterpret_cast<const uint4 *>(tab + table_segs_off(K));
-  unsigned __int128 r, hd;
-  asm volatile("s_load_dwordx4 %0, %2, 0x10\n\ts_load_dwordx4 %1, %3, 0x0" : "=&s"(hd), "=&s"(r) : "s"((unsigned long long)tab), "s"((unsigned long long)segs));
-  const ImageDesc d = batch.img[img_i];
-  asm volatile("" ::"s"(d.in), "s"(d.out), "s"(d.C), "s"(d.H), "s"(d.W), "s"(d.table), "s"(d.tiles_x), "s"(d.tiles_y),
-               "s"(d.inv_per_ch), "s"(d.inv_tiles_x), "s"(d.tab));
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hd), "+s"(r));
-  const int per_ch = d.tiles_x * d.tiles_y;
-  int local;
-  if (!band_entry(d.C * per_ch, blockIdx.x & 7, entry, local)) return;
-  const int ch = magic_div(local, d.inv_per_ch);
-  local -= ch * per_ch;
-  const int ty = magic_div(local, d.inv_tiles_x), tx = local - ty * d.tiles_x;
-  blur_quad_tile_f16<ACC, false, false, NoWait, false, true>(d, tab, K, ch, tx, ty, lds_addr(nlds), __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6),
-                                                             (int)(unsigned)(hd >> 32), (int)(unsigned)(hd >> 96),
-                                                             make_uint4((unsigned)r, (unsigned)(r >> 32), (unsigned)(r >> 64), (unsigned)(r >> 96)));
-}
-template __global__ void blur_quad_f16_pre_kernel<DIB_ACC_BITEXACT>(const int *, BlurBatch);
-template __global__ void blur_quad_f16_pre_kernel<DIB_ACC_FAST16>(const int *, BlurBatch);
-#endif
 
 // =============================================================================================
 // The blur STEP as ONE launch (dib_blur_step: tap compaction + blur; reference models/blur_functions.py:92-100).
@@ -2034,15 +1997,6 @@ extern "C" int dib_sparse_blur(const void *const *in_dev, void *const *out_dev, 
           fb.rev_mask = g_flat_mask >= 0 ? (unsigned)g_flat_mask : (g_flat_snake && acc_mode == DIB_ACC_BITEXACT ? 0xffffffffu : 0u);
         }
       }
-#ifdef DIB_EXP_PRELOAD
-      static const int preload = getenv("DIB_PRELOAD") ? atoi(getenv("DIB_PRELOAD")) : 0;
-      if (preload && quad && !large && !flat && K == 128 && (acc_mode == DIB_ACC_BITEXACT || acc_mode == DIB_ACC_FAST16)) {
-        if (acc_mode == DIB_ACC_FAST16) hipLaunchKernelGGL((blur_quad_f16_pre_kernel<DIB_ACC_FAST16>), grid, dim3(256), QLDS_BYTES, s, (const int *)tables_dev, tiled);
-        else hipLaunchKernelGGL((blur_quad_f16_pre_kernel<DIB_ACC_BITEXACT>), grid, dim3(256), QLDS_BYTES, s, (const int *)tables_dev, tiled);
-        DIB_HIP_CHECK(hipGetLastError());
-        continue;
-      }
-#endif
 #define DIB_LAUNCH_QUAD(ACCM)                                                                                             \
   do {                                                                                                                   \
     if (large && K == 128) hipLaunchKernelGGL((blur_quad_large_f16_kernel<ACCM, 128>), grid, dim3(256), QGeom<true>::BYTES, s, tiled); \
